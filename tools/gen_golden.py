@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ FROM THE REFERENCE.  Runs only in the build
+container (it needs /root/reference); the fixtures it writes are data (inputs + expected outputs) and
+are what travels to the GPU box.
+
+How the reference is run here
+  * Its own Python is imported from /root/reference: `mm_utils.tokenizer_seq_token`,
+    `OpusLlamaForCausalLM` (prepare_inputs_labels_for_multimodal / generate), `CSTPBase.protein_forward`,
+    `build_switch_projector`.
+  * Two third-party modules it imports are not installed (requirements.txt:6 `fair_esm`, and
+    `pytorch_lightning`); empty in-memory placeholders satisfy the import statements - no
+    code of theirs is on the golden path: the ESM-2 encoder arithmetic is taken from the local
+    `transformers` EsmModel (same published architecture) wrapped in a fake encoder object that follows
+    cstp_v3/modelling.py:37-57, and the decoder is the reference class itself (it subclasses the local
+    transformers LlamaForCausalLM).
+  * `OpusLlamaForCausalLM.prepare_inputs_for_generation` was written for transformers 4.46.3 and pops a
+    key that 5.15 no longer returns (opus_llama.py:141); it is rebound in THIS process to the parent
+    implementation - /root/reference is never modified.
+Weights are the deterministic synthetic tensors of opus_pllm_amd.synth, so fixtures store seeds, inputs and
+expected outputs only.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+warnings.filterwarnings("ignore")
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+# --- placeholders for absent third-party imports (see module docstring) -------------------------
+sys.modules.setdefault("esm", types.ModuleType("esm"))
+_pl = types.ModuleType("pytorch_lightning")
+_pl.LightningModule = torch.nn.Module
+sys.modules.setdefault("pytorch_lightning", _pl)
+
+import opus_pllm_amd as opa                                            # noqa: E402
+from opus_pllm_amd import synth                                        # noqa: E402
+from multi_modality_model.multi_modality_v1 import mm_utils as ref_mm  # noqa: E402
+from multi_modality_model.multi_modality_v1.model.language_model.opus_llama import (  # noqa: E402
+    OpusLlamaForCausalLM, OpusLlamaConfig)
+from multi_modality_model.cstp_v3.modelling import CSTPBase            # noqa: E402
+from multi_modality_model.multi_modality_v1.model.protein_mlp.builder import build_switch_projector  # noqa: E402
+from transformers import EsmConfig, EsmModel, LlamaForCausalLM        # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------
+class FakeTokenizer:
+    """Whitespace tokenizer with a BOS: enough for tokenizer_seq_token (mm_utils.py:12-32)."""
+
+    def __init__(self, add_bos=True, bos_token_id=1):
+        self.add_bos, self.bos_token_id = add_bos, bos_token_id
+
+    def __call__(self, text):
+        ids = [3 + (sum(ord(c) * (i + 1) for i, c in enumerate(w)) % 90) for w in text.split()]
+        return types.SimpleNamespace(input_ids=([self.bos_token_id] if self.add_bos else []) + ids)
+
+
+def tw(w, name):
+    return torch.from_numpy(np.ascontiguousarray(w[name])).float()
+
+
+def build_hf_esm(cfg, w) -> EsmModel:
+    ec = EsmConfig(vocab_size=cfg.enc_vocab, hidden_size=cfg.enc_dim, num_hidden_layers=cfg.enc_layers,
+                   num_attention_heads=cfg.enc_heads, intermediate_size=cfg.enc_ffn,
+                   position_embedding_type="rotary", token_dropout=True, emb_layer_norm_before=False,
+                   pad_token_id=1, mask_token_id=32, layer_norm_eps=cfg.enc_ln_eps,
+                   hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ec._attn_implementation = "eager"
+    m = EsmModel(ec, add_pooling_layer=False).eval()
+    sd = {"embeddings.word_embeddings.weight": tw(w, "enc.embed_tokens"),
+          "encoder.emb_layer_norm_after.weight": tw(w, "enc.ln_f.weight"),
+          "encoder.emb_layer_norm_after.bias": tw(w, "enc.ln_f.bias")}
+    for l in range(cfg.enc_layers):
+        s, d = f"enc.layers.{l}.", f"encoder.layer.{l}."
+        for a, b in (("ln1", "attention.LayerNorm"), ("q", "attention.self.query"), ("k", "attention.self.key"),
+                     ("v", "attention.self.value"), ("o", "attention.output.dense"), ("ln2", "LayerNorm"),
+                     ("fc1", "intermediate.dense"), ("fc2", "output.dense")):
+            sd[d + b + ".weight"] = tw(w, s + a + ".weight")
+            sd[d + b + ".bias"] = tw(w, s + a + ".bias")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    bad = [k for k in missing if "inv_freq" not in k and "position_embeddings" not in k
+           and "position_ids" not in k and "contact_head" not in k]
+    assert not bad and not unexpected, (bad, unexpected)
+    return m
+
+
+class FakeEncoder:
+    """get_protein_seq_embeddings per cstp_v3/modelling.py:37-57, ESM-2 arithmetic by HF EsmModel."""
+
+    def __init__(self, hf_esm):
+        self.model = hf_esm
+
+    def tokens(self, seqs):
+        toks, _ = opa.alphabet.batch_convert(seqs) if hasattr(opa, "alphabet") else (None, None)
+        return toks
+
+    def get_protein_seq_embeddings(self, data):
+        from opus_pllm_amd.alphabet import batch_convert, PAD_IDX
+        toks, _ = batch_convert(data)
+        batch_tokens = torch.from_numpy(toks).long()
+        batch_lens = (batch_tokens != PAD_IDX).sum(1)                         # modelling.py:45
+        with torch.no_grad():
+            rep = self.model(input_ids=batch_tokens, attention_mask=(batch_tokens != PAD_IDX).long()
+                             ).last_hidden_state                              # representations[n_layers]
+        out = [rep[i, 1: n - 1].mean(0) for i, n in enumerate(batch_lens)]    # modelling.py:52-54
+        return torch.stack(out).float()
+
+
+def build_ref_model(cfg, w, encoder) -> OpusLlamaForCausalLM:
+    lc = OpusLlamaConfig(vocab_size=cfg.dec_vocab, hidden_size=cfg.dec_dim, intermediate_size=cfg.dec_ffn,
+                         num_hidden_layers=cfg.dec_layers, num_attention_heads=cfg.dec_heads,
+                         num_key_value_heads=cfg.dec_kv_heads, head_dim=cfg.dec_head_dim,
+                         rms_norm_eps=cfg.dec_rms_eps, rope_theta=cfg.dec_rope_theta,
+                         max_position_embeddings=2048, tie_word_embeddings=False, attention_bias=False,
+                         pad_token_id=None, bos_token_id=1, eos_token_id=None)
+    lc._attn_implementation = "eager"
+    model = OpusLlamaForCausalLM(lc).eval()
+    sd = {"model.embed_tokens.weight": tw(w, "dec.embed_tokens"), "model.norm.weight": tw(w, "dec.norm.weight"),
+          "lm_head.weight": tw(w, "dec.lm_head.weight")}
+    for l in range(cfg.dec_layers):
+        s, d = f"dec.layers.{l}.", f"model.layers.{l}."
+        sd[d + "input_layernorm.weight"] = tw(w, s + "input_norm.weight")
+        sd[d + "post_attention_layernorm.weight"] = tw(w, s + "post_norm.weight")
+        for a in ("q", "k", "v", "o"):
+            sd[d + f"self_attn.{a}_proj.weight"] = tw(w, s + a + ".weight")
+        for a in ("gate", "up", "down"):
+            sd[d + f"mlp.{a}_proj.weight"] = tw(w, s + a + ".weight")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing if "inv_freq" not in k] and not unexpected, (missing, unexpected)
+    # protein modules, wired the way initialize_protein_modules does (opus_arch.py:46-90)
+    inner = model.get_model()
+    inner.protein_encoder = encoder
+    proj = CSTPBase(cfg.enc_dim, cfg.proj_dim, cfg.proj_dim, cfg.proj_dim, 8, 1, 0.5).eval()
+    proj.protein_projection.linear.weight.data = tw(w, "proj.weight")
+    proj.protein_projection.linear.bias.data = tw(w, "proj.bias")
+    inner.protein_projector = proj
+    margs = types.SimpleNamespace(hidden_size=cfg.dec_dim, pretrain_protein_projector_ckpt="x",
+                                  switch_projector_type="mlp%dx_gelu" % cfg.switch_depth
+                                  if cfg.switch_depth > 1 else "linear")
+    sw = build_switch_projector(margs, n_tokens=cfg.n_prot_tokens)
+    # Switch_Arguments.mm_hidden_size is hard-coded to 5120 (protein_mlp/builder.py:14); the micro
+    # configs use a smaller projector width, so rebuild the first Linear at the configured width.
+    lin = [m for m in (sw if isinstance(sw, torch.nn.Sequential) else [sw]) if isinstance(m, torch.nn.Linear)]
+    if lin[0].in_features != cfg.switch_in:
+        first = torch.nn.Linear(cfg.switch_in, cfg.switch_out)
+        if isinstance(sw, torch.nn.Sequential):
+            sw[0] = first
+        else:
+            sw = first
+        lin[0] = first
+    for i, m in enumerate(lin):
+        m.weight.data = tw(w, f"switch.{i}.weight")
+        m.bias.data = tw(w, f"switch.{i}.bias")
+    inner.switch_projector = sw.eval()
+    model.config.has_switch_projector = True
+    model.config.has_protein_encoder = True
+
+    def _prep(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
+        seq = kwargs.pop("seq", None)
+        inputs = LlamaForCausalLM.prepare_inputs_for_generation(
+            self, input_ids, past_key_values=past_key_values, inputs_embeds=inputs_embeds, **kwargs)
+        inputs.pop("cache_position", None)
+        if seq is not None:
+            inputs["seq"] = seq
+        return inputs
+    OpusLlamaForCausalLM.prepare_inputs_for_generation = _prep
+    return model
+
+
+def save(name, **arrs):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------------
+def gold_tokenizer():
+    cases = []
+    prompts = ["hello <seq> world", "<seq>\nwhat is this protein", "no placeholder here",
+               "two <seq> place <seq> holders", "<seq>", "", "tail <seq>"]
+    for add_bos in (True, False):
+        tok = FakeTokenizer(add_bos)
+        for p in prompts:
+            ids = ref_mm.tokenizer_seq_token(p, tok, -200)
+            pt = ref_mm.tokenizer_seq_token(p, tok, -200, return_tensors="pt")
+            assert pt.tolist() == ids and pt.dtype == torch.long
+            cases.append(dict(prompt=p, add_bos=add_bos, ids=ids))
+    try:
+        ref_mm.tokenizer_seq_token("a", FakeTokenizer(), -200, return_tensors="np")
+        raised = None
+    except ValueError as e:
+        raised = str(e)
+    with open(os.path.join(GOLD, "tokenizer_seq_token.json"), "w") as f:
+        json.dump(dict(cases=cases, bad_tensor_type_error=raised), f, indent=1)
+    print("  wrote tests/golden/tokenizer_seq_token.json")
+
+
+def gold_splice(cfg, w, model):
+    """prepare_inputs_labels_for_multimodal on hand-built batches; protein blocks injected via
+    seq_embedding-free path is impossible without an encoder, so the encoder is a stub returning
+    fixed pooled vectors and the blocks are recomputed by the reference projector modules."""
+    rng = np.random.default_rng(5)
+    V = cfg.dec_vocab
+    out = {}
+
+    def case(tag, rows, pad_id, inference_mode, with_labels=False, with_mask=True):
+        width = max(len(r) for r in rows)
+        ids = torch.full((len(rows), width), pad_id, dtype=torch.long)
+        for i, r in enumerate(rows):
+            if len(r):
+                ids[i, width - len(r):] = torch.tensor(r)
+        mask = ids != pad_id
+        n_prot = sum(max(1, sum(1 for t in r if t == -200)) for r in rows)
+        pooled = torch.from_numpy(rng.standard_normal((n_prot, cfg.enc_dim)).astype(np.float32))
+
+        class Stub:
+            def get_protein_seq_embeddings(self, data):
+                return pooled
+        model.get_model().protein_encoder = Stub()
+        labels = None
+        if with_labels:
+            labels = torch.where(ids == -200, torch.full_like(ids, -100), ids)
+        with torch.no_grad():
+            res = model.prepare_inputs_labels_for_multimodal(
+                ids, None, mask if with_mask else None, None, labels, ["X"] * n_prot,
+                inference_mode=inference_mode)
+            prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+        _, pos, amask, _, emb, lab = res
+        out[tag + ".ids"] = ids.numpy()
+        out[tag + ".mask_in"] = mask.numpy()
+        out[tag + ".pooled"] = pooled.numpy()
+        out[tag + ".prot"] = prot.numpy()
+        out[tag + ".embeds"] = emb.numpy()
+        out[tag + ".mask_out"] = (amask.numpy() if amask is not None else np.zeros((0,), bool))
+        out[tag + ".pos_is_none"] = np.array(pos is None)
+        out[tag + ".labels"] = (lab.numpy() if lab is not None else np.zeros((0,), np.int64))
+        out[tag + ".inference_mode"] = np.array(inference_mode)
+        out[tag + ".with_mask"] = np.array(with_mask)
+
+    r = lambda n: [int(x) for x in rng.integers(3, V, n)]          # noqa: E731
+    case("one_each", [[1] + r(5) + [-200] + r(3), [1] + r(2) + [-200] + r(9), [1, -200] + r(4)], 2, True)
+    case("ragged_zero_two", [[1] + r(6), [1] + r(1) + [-200] + r(2) + [-200] + r(3), [1] + r(3) + [-200]], 2, True)
+    case("right_pad_labels", [[1] + r(5) + [-200] + r(3), [1] + r(2) + [-200] + r(6)], 2, False, with_labels=True)
+    case("no_mask", [[1] + r(4) + [-200] + r(4), [1] + r(4) + [-200] + r(4)], 2, True, with_mask=False)
+    case("single", [[1] + r(7) + [-200] + r(2)], 2, True)
+    save("splice", **out)
+
+
+def gold_projector(cfg, w, model):
+    x = torch.from_numpy(np.random.default_rng(11).standard_normal((5, cfg.enc_dim)).astype(np.float32)) * 3.0
+    x[3] = 0.0                                                     # exercises the 1e-12 clamp of F.normalize
+    with torch.no_grad():
+        y = model.encode_projector_embedding(x)
+        z = model.switch_projector_embedding(y)
+    save("projector", pooled=x.numpy(), proj=y.numpy(), prot=z.numpy())
+
+
+def gold_esm(tag, cfg, w, seqs):
+    from opus_pllm_amd.alphabet import batch_convert
+    hf = build_hf_esm(cfg, w)
+    toks, lens = batch_convert(seqs)
+    t = torch.from_numpy(toks).long()
+    with torch.no_grad():
+        o = hf(input_ids=t, attention_mask=(t != 1).long(), output_hidden_states=True)
+    hs = o.hidden_states                                            # embeddings + one per layer
+    pooled = FakeEncoder(hf).get_protein_seq_embeddings(seqs)
+    arrs = dict(tokens=toks, lens=lens, pooled=pooled.numpy(),
+                last_hidden=o.last_hidden_state.numpy().astype(np.float32) if t.numel() * cfg.enc_dim < 3e5
+                else np.zeros((0,), np.float32),
+                layer_abs_mean=np.array([float(h[t != 1].abs().mean()) for h in hs], np.float64),
+                layer_sum=np.array([float(h[t != 1].double().sum()) for h in hs], np.float64))
+    save(tag, **arrs)
+    with open(os.path.join(GOLD, tag + ".seqs.json"), "w") as f:
+        json.dump(seqs, f)
+    return hf
+
+
+def gold_llama_and_generate(cfg, w, model, hf_esm):
+    V = cfg.dec_vocab
+    rng = np.random.default_rng(3)
+    model.get_model().protein_encoder = FakeEncoder(hf_esm)
+    seqs = [synth.synth_protein(n, i) for i, n in enumerate((23, 40, 9))]
+    r = lambda n: [int(x) for x in rng.integers(3, V, n)]          # noqa: E731
+    rows = [[1] + r(6) + [-200] + r(4), [1] + r(3) + [-200] + r(9), [1, -200] + r(5)]
+    pad = 2
+    width = max(len(x) for x in rows)
+    ids = torch.full((len(rows), width), pad, dtype=torch.long)
+    for i, x in enumerate(rows):
+        ids[i, width - len(x):] = torch.tensor(x)
+    mask = ids != pad
+    N = 12
+    with torch.no_grad():
+        free = model.generate(ids, seqs, attention_mask=mask, pad_token_id=pad, do_sample=False,
+                              max_new_tokens=N, use_cache=True, eos_token_id=None)
+        # an EOS that row 1 emits at step 4 (and nobody earlier) -> EOS-then-pad behaviour
+        eos = int(free[1, 4])
+        with_eos = model.generate(ids, seqs, attention_mask=mask, pad_token_id=pad, do_sample=False,
+                                  max_new_tokens=N, use_cache=True, eos_token_id=[eos])
+        # prefill logits + teacher-forced decode logits through the reference forward
+        _, _, amask, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, None, seqs,
+                                                                            inference_mode=True)
+        full = torch.cat([emb, model.get_model().embed_tokens(free[:, :4])], dim=1)
+        fmask = torch.cat([amask, torch.ones(len(rows), 4, dtype=amask.dtype)], dim=1)
+        posid = (fmask.long().cumsum(-1) - 1).clamp(min=0)
+        logits = LlamaForCausalLM.forward(model, inputs_embeds=full, attention_mask=fmask.long(),
+                                          position_ids=posid).logits
+        T = emb.shape[1]
+    save("generate_micro", ids=ids.numpy(), mask=mask.numpy(), pad=np.array(pad), eos=np.array(eos),
+         free_ids=free.numpy(), eos_ids_out=with_eos.numpy(), embeds=emb.numpy(), mask_out=amask.numpy(),
+         step_logits=logits[:, T - 1:T + 4].numpy())
+    with open(os.path.join(GOLD, "generate_micro.seqs.json"), "w") as f:
+        json.dump(seqs, f)
+
+
+def gold_c1(cfg, w):
+    """(vii) full C1 chain: one 128-residue protein, ESM2-t6-8M shape + tiny decoder, greedy ids."""
+    hf = gold_esm("esm_c1", cfg, w, [synth.synth_protein(128, 0)])
+    model = build_ref_model(cfg, w, FakeEncoder(hf))
+    prompt = synth.synth_prompt_ids(cfg.dec_vocab, 0, n_text=24, seq_pos=9)
+    ids = torch.tensor([prompt])
+    with torch.no_grad():
+        out = model.generate(ids, [synth.synth_protein(128, 0)], attention_mask=torch.ones_like(ids).bool(),
+                             pad_token_id=2, do_sample=False, max_new_tokens=16, use_cache=True, eos_token_id=None)
+    save("generate_c1", ids=ids.numpy(), out_ids=out.numpy())
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    print("tokenizer_seq_token"); gold_tokenizer()
+    cfg = opa.micro()
+    w = synth.canonical_weights(cfg, seed=0)
+    print("esm micro")
+    seqs = [synth.synth_protein(n, i) for i, n in enumerate((17, 33, 5, 64))]
+    hf = gold_esm("esm_micro", cfg, w, seqs)
+    model = build_ref_model(cfg, w, FakeEncoder(hf))
+    print("projector"); gold_projector(cfg, w, model)
+    print("splice"); gold_splice(cfg, w, model)
+    print("llama + generate (micro)"); gold_llama_and_generate(cfg, w, model, hf)
+    print("C1 chain")
+    c1 = opa.c1_tiny()
+    gold_c1(c1, synth.canonical_weights(c1, seed=0))
+    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
+        json.dump(dict(generator="tools/gen_golden.py", weights_seed=0, torch=torch.__version__,
+                       transformers=__import__("transformers").__version__,
+                       reference="/root/reference (Fanchuana/OPUS-PLLM @ 2026-05-29)"), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
