@@ -1,0 +1,160 @@
+/*
+ * opus_pllm.h - C ABI of the MI355X-native multi_modality_v1 inference path (libopus_pllm.so).
+ *
+ * The reference (Fanchuana/OPUS-PLLM) has no plugin / FFI interface: its boundary is the Python call
+ * surface used by the eval scripts.  This header is the boundary a binding for that surface
+ * uses; every entry point cites the reference code it replaces.  The Python shim in
+ * opus-pllm_amd/_cabi.py binds exactly these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - extern "C", plain C types, opaque opus_ctx*; no C++ exception crosses the boundary.
+ *   - Every function returns 0 (OPUS_OK) or a negative error class; the message is available from
+ *     opus_last_error() (thread-local).
+ *   - All pointers named d_* are DEVICE pointers owned by the caller (PyTorch keeps ownership and
+ *     lifetime of weights and I/O buffers); the library owns only the context, its workspace and
+ *     its KV cache, all sized at opus_ctx_create from the config's capacity fields.
+ *   - All work is ordered on the caller's hipStream_t (passed as void*; NULL = default stream).
+ *     No hidden device synchronisation, except where a function returns a HOST scalar that depends
+ *     on device data (documented per function: it synchronises the given stream once).
+ *   - A context is bound to one device and is not thread-safe: one per process, as the reference's
+ *     one-process-per-GPU model (model/builder.py:41).
+ */
+#ifndef OPUS_PLLM_H
+#define OPUS_PLLM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPUS_ABI_VERSION 1
+
+enum opus_status {
+    OPUS_OK = 0,
+    OPUS_EBADARG = -1,      /* null pointer, bad enum, negative size */
+    OPUS_ESHAPE = -2,       /* shape exceeds the context capacity or violates a kernel granule */
+    OPUS_EHIP = -3,         /* a HIP runtime call failed */
+    OPUS_ERCCL = -4,        /* reserved: collective failure */
+    OPUS_EUNSUPPORTED = -5, /* valid request the build does not implement */
+    OPUS_ESTATE = -6        /* missing weights / call out of order */
+};
+
+enum opus_dtype { OPUS_F16 = 0, OPUS_F32 = 1, OPUS_I32 = 2, OPUS_I64 = 3, OPUS_U8 = 4 };
+
+/* Shapes of the path.  The reference hard-codes or threads these through a global class
+ * (model/builder.py:24-28, protein_projector/builder.py:7-13, protein_mlp/builder.py:11-15,
+ * cstp_v3/modelling.py:21); here they are explicit.  Field order == opus-pllm_amd/config.py. */
+typedef struct opus_config {
+    int32_t enc_layers, enc_dim, enc_heads, enc_ffn, enc_vocab;
+    float enc_ln_eps, enc_rope_theta;
+    int32_t has_protein_projector, proj_dim, n_prot_tokens, switch_depth;
+    int32_t dec_layers, dec_dim, dec_heads, dec_kv_heads, dec_head_dim, dec_ffn, dec_vocab;
+    float dec_rms_eps, dec_rope_theta;
+    int32_t max_batch, max_enc_tokens, max_prompt, max_new_tokens;
+} opus_config;
+
+typedef struct opus_ctx opus_ctx;
+
+int opus_abi_version(void);
+const char *opus_last_error(void);
+
+/* Bytes of device memory opus_ctx_create will allocate for this config (workspace + KV cache). */
+int64_t opus_workspace_bytes(const opus_config *cfg);
+
+/* Replaces the module construction of load_pretrained_model / initialize_protein_modules
+ * (model/builder.py:29-131, model/opus_arch.py:46-90): creates the per-process context on `device`. */
+int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **out);
+int opus_ctx_destroy(opus_ctx *ctx);
+
+/* Bind one weight tensor (borrowed device pointer).  Names and layouts: DESIGN.md "Weights in HBM"
+ * (fused [q;k;v] rows, gate/up interleaved in 16-row groups).  Replaces the state-dict loads of
+ * model/builder.py:60-65,107-111 and opus_arch.py:81-90.  fp16 for matrices, fp32 for vectors. */
+int opus_bind_weight(opus_ctx *ctx, const char *name, const void *d_ptr, int dtype, int ndim,
+                     const int64_t *shape);
+/* 0 when every tensor the config requires is bound; otherwise OPUS_ESTATE and the first missing
+ * name in opus_last_error(). */
+int opus_weights_ready(opus_ctx *ctx);
+
+/* Row L1: PeftModel.merge_and_unload (model/builder.py:107-109): W[out,in] += scale * B[out,r] A[r,in],
+ * fp16 weights, fp32 accumulation, in place. */
+int opus_lora_merge(void *d_W, const void *d_A, const void *d_B, float scale, int64_t out_f, int64_t in_f,
+                    int32_t r, void *stream);
+
+/* Deterministic synthetic tensor fill (no checkpoints exist offline; opus-pllm_amd/synth.py is the
+ * NumPy twin, bit-identical).  Element (row, col) of the LOGICAL [rows, cols] tensor is written at
+ * dst row (row / row_block) * row_stride + row_off + row % row_block. */
+int opus_fill_synth(void *d_dst, int dtype, int64_t rows, int64_t cols, uint64_t tensor_seed, float std,
+                    float mean, int64_t row_block, int64_t row_stride, int64_t row_off, void *stream);
+
+/* Rows E1-E4: ProteinSeqEmbeddingExtractor.get_protein_seq_embeddings (cstp_v3/modelling.py:37-57):
+ * tokens int32 [B,T] (<cls> seq <eos>, pad = 1), lens int32 [B] (incl. <cls>,<eos>) ->
+ * pooled fp32 [B, enc_dim] = mean over residues of representations[enc_layers]. */
+int opus_esm2_encode(opus_ctx *ctx, const int32_t *d_tokens, const int32_t *d_lens, int32_t B, int32_t T,
+                     float *d_pooled, void *stream);
+/* Debug/parity tap: copy of representations[enc_layers] fp32 [B,T,enc_dim] of the last encode. */
+int opus_esm2_last_hidden(opus_ctx *ctx, float *d_out, int32_t B, int32_t T, void *stream);
+
+/* Rows P1+P2: encode_projector_embedding + switch_projector_embedding (opus_arch.py:115-131,
+ * modelling.py:396-400, protein_mlp/builder.py:11-25): pooled fp32 [B,enc_dim] ->
+ * fp16 [B, n_prot_tokens, dec_dim].  d_proj_out (optional, may be NULL) receives the P1 output
+ * fp16 [B, proj_dim]. */
+int opus_projector_forward(opus_ctx *ctx, const float *d_pooled, int32_t B, void *d_out, void *d_proj_out,
+                           void *stream);
+/* Row P1 alone: encode_projector_embedding (opus_arch.py:115-121): fp32 [B,enc_dim] -> fp16 [B,proj_dim]. */
+int opus_protein_projector(opus_ctx *ctx, const float *d_pooled, int32_t B, void *d_out, void *stream);
+/* Row P2 alone: switch_projector_embedding (opus_arch.py:122-131): fp16 [B,switch_in] -> fp16 [B,n,H]. */
+int opus_switch_projector(opus_ctx *ctx, const void *d_in, int32_t B, void *d_out, void *stream);
+
+/* Rows S1-S3: the splice of prepare_inputs_labels_for_multimodal (opus_arch.py:166-270).
+ * ids int64 [B,T_text] (-200 = <seq>), mask u8 [B,T_text] (NULL = all ones), prot fp16
+ * [n_prot, n_prot_tokens, dec_dim] consumed in order (a row without placeholder consumes one).
+ * Outputs sized for max_prompt: embeds fp16 [B,T_out,H] (zeros in pad slots), mask u8 [B,T_out],
+ * pos int32 [B,T_out].  T_out is a HOST int: the call synchronises `stream` once to return it.
+ * max_length > 0 truncates rows (config.tokenizer_model_max_length, :234-237).
+ * Errors: OPUS_ESHAPE when fewer protein blocks are supplied than the rows consume, or T_out
+ * exceeds max_prompt. */
+int opus_splice_pad(opus_ctx *ctx, const int64_t *d_ids, const uint8_t *d_mask, int32_t B, int32_t T_text,
+                    const void *d_prot, int32_t n_prot, int32_t inference_mode, int32_t max_length,
+                    void *d_embeds, uint8_t *d_mask_out, int32_t *d_pos_out, int32_t *T_out, void *stream);
+
+/* Rows D1,D2,D4: LlamaForCausalLM prefill as called by generate (language_model/opus_llama.py:127-132):
+ * embeds fp16 [B,T,H], mask u8 [B,T] (left-padded rows) -> logits of the LAST position fp32 [B,V];
+ * fills the context's KV cache and resets its step counter. */
+int opus_llama_prefill(opus_ctx *ctx, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
+                       float *d_last_logits, void *stream);
+/* Row D3: one decode step for the B rows of the last prefill: tok int32 [B] -> logits fp32 [B,V]. */
+int opus_llama_decode_step(opus_ctx *ctx, const int32_t *d_tok, float *d_logits, void *stream);
+
+/* Rows G1 (+D1-D4): greedy search of GenerationMixin as driven by opus_llama.py:95-132.
+ * next = argmax(last logits); finished rows emit pad_id; a row finishes on any of eos_ids (host
+ * array, may be empty); stops when all rows are finished or after max_new steps.
+ * out ids int32 [B,max_new] (device; unused tail = pad_id); n_out (HOST) = steps produced, the
+ * second dimension HF would return.  Synchronises `stream` (it returns a host scalar). */
+int opus_generate_greedy(opus_ctx *ctx, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
+                         int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id,
+                         int32_t *d_out_ids, int32_t *n_out, void *stream);
+
+/* Diagnostic entry points (kernel-level parity tests and micro-benchmarks; not part of the path's
+ * drop-in surface).  opus_debug_gemm: C[M,Nout] = epi(A[M,K] W[N,K]^T + bias) (+ residual fp32);
+ * epi 0 none, 1 erf-GELU, 2 silu(gate)*up with W rows in [16 gate | 16 up] groups (Nout = N/2).
+ * opus_debug_attention: softmax(scale * Q K^T + mask) V over [B,T,heads*hd] fp16 tensors
+ * (K,V have heads/group heads); keys visible iff kstart[b] <= j < kend[b] (NULL = 0 / T) and
+ * (!causal || j <= i). */
+int opus_debug_gemm(opus_ctx *ctx, const void *d_A, const void *d_W, const float *d_bias, const float *d_residual,
+                    void *d_C, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t out_f32, void *stream);
+int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const void *d_V, void *d_O,
+                         const int32_t *d_kstart, const int32_t *d_kend, int32_t B, int32_t T, int32_t heads,
+                         int32_t group, int32_t head_dim, int32_t causal, float scale, void *stream);
+
+/* Measurement support (bench.py): cumulative device time in ms of one kernel class since the last
+ * reset, measured with hipEvents on the launch stream when timing is enabled (off by default).
+ * class names: "skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other". */
+int opus_timing_enable(opus_ctx *ctx, int32_t on);
+int opus_timing_reset(opus_ctx *ctx);
+int opus_timing_get(opus_ctx *ctx, const char *kernel_class, double *ms, int64_t *launches, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPUS_PLLM_H */

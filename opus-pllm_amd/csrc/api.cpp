@@ -1,0 +1,763 @@
+// C ABI + runtime of libopus_pllm.so: context, weight registry, workspace / KV cache, the kernel
+// sequences of the path (encoder, projectors, splice, prefill, decode), the on-device greedy loop
+// with hipGraph replay of the decode step, and per-kernel-class event timing for bench.py.
+#include "../../include/opus_pllm.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace opus;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPC(expr)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail(OPUS_EHIP, "%s failed: %s (%s:%d)", #expr,                 \
+                                          hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+#define OPC(expr)                  \
+    do {                           \
+        int r_ = (expr);           \
+        if (r_ != OPUS_OK) return r_; \
+    } while (0)
+
+struct Tensor {
+    const void *p = nullptr;
+    int dtype = -1;
+    std::vector<int64_t> shape;
+};
+
+struct EncLayer {
+    const float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2;
+    const half_t *wqkv, *wo, *w1, *w2;
+};
+struct DecLayer {
+    const float *ln1, *ln2;
+    const half_t *wqkv, *wo, *wgu, *wd;
+};
+
+struct TimeRec {
+    int klass;
+    hipEvent_t e0, e1;
+    double bytes;
+};
+
+struct opus_ctx {
+    opus_config cfg;
+    int device = 0;
+    std::map<std::string, Tensor> w;
+    bool resolved = false;
+    // resolved weights
+    const half_t *enc_emb = nullptr, *dec_emb = nullptr, *lm_head = nullptr, *proj_w = nullptr;
+    const float *enc_lnfw = nullptr, *enc_lnfb = nullptr, *dec_lnf = nullptr, *proj_b = nullptr;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    std::vector<const half_t *> sw_w;
+    std::vector<const float *> sw_b;
+    // workspace
+    char *ws = nullptr;
+    size_t ws_bytes = 0;
+    float *e_x, *e_hid, *p_pool_dummy;
+    half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
+    half_t *p_xn, *p_y, *p_z[2];
+    float *d_x, *d_xl, *d_logits;
+    half_t *d_xn, *d_qkv, *d_ctx, *d_act, *d_xln, *kc, *vc;
+    float *cs_enc, *cs_dec;
+    int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan;
+    int64_t cache_sl, cache_sb, cache_sh;   // strides (halfs): layer, batch row, kv head
+    // decode state
+    int cur_B = 0, cur_T = 0;
+    bool prefilled = false;
+    // graph cache for the decode iteration
+    hipGraphExec_t gexec = nullptr;
+    int g_B = -1, g_T = -1, g_maxnew = -1, g_pad = 0, g_neos = -1;
+    const int32_t *g_out = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<TimeRec> recs;
+};
+
+// ------------------------------------------------------------------------------------------------
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <class T>
+    T *take(size_t n) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += align_up(n * sizeof(T));
+        return p;
+    }
+};
+
+static void carve(opus_ctx *c, char *base, size_t *total) {
+    const opus_config &g = c->cfg;
+    Carver k{base};
+    const size_t Me = (size_t)g.max_batch * g.max_enc_tokens;
+    const size_t De = g.enc_dim, Fe = g.enc_ffn;
+    c->e_x = k.take<float>(Me * De);
+    c->e_hid = k.take<float>(Me * De);
+    c->e_xn = k.take<half_t>(Me * De);
+    c->e_qkv = k.take<half_t>(Me * 3 * De);
+    c->e_ctx = k.take<half_t>(Me * De);
+    c->e_h1 = k.take<half_t>(Me * Fe);
+    const size_t B = g.max_batch, H = g.dec_dim, SW = (size_t)g.dec_dim * g.n_prot_tokens;
+    c->p_xn = k.take<half_t>(B * De);
+    c->p_y = k.take<half_t>(B * (size_t)(g.has_protein_projector ? g.proj_dim : g.enc_dim));
+    c->p_z[0] = k.take<half_t>(B * SW);
+    c->p_z[1] = k.take<half_t>(B * SW);
+    const size_t Md = B * g.max_prompt;
+    const size_t QKV = (size_t)(g.dec_heads + 2 * g.dec_kv_heads) * g.dec_head_dim;
+    const size_t QD = (size_t)g.dec_heads * g.dec_head_dim;
+    c->d_x = k.take<float>(Md * H);
+    c->d_xn = k.take<half_t>(Md * H);
+    c->d_qkv = k.take<half_t>(Md * QKV);
+    c->d_ctx = k.take<half_t>(Md * QD);
+    c->d_act = k.take<half_t>(Md * g.dec_ffn);
+    c->d_xl = k.take<float>(B * H);
+    c->d_xln = k.take<half_t>(B * H);
+    c->d_logits = k.take<float>(B * (size_t)g.dec_vocab);
+    const size_t ctx = (size_t)g.max_prompt + g.max_new_tokens;
+    c->cache_sh = (int64_t)ctx * g.dec_head_dim;
+    c->cache_sb = c->cache_sh * g.dec_kv_heads;
+    c->cache_sl = c->cache_sb * g.max_batch;
+    c->kc = k.take<half_t>((size_t)c->cache_sl * g.dec_layers);
+    c->vc = k.take<half_t>((size_t)c->cache_sl * g.dec_layers);
+    const size_t maxpos_e = g.max_enc_tokens, maxpos_d = ctx;
+    c->cs_enc = k.take<float>(maxpos_e * (g.enc_dim / g.enc_heads));
+    c->cs_dec = k.take<float>(maxpos_d * g.dec_head_dim);
+    c->d_kstart = k.take<int32_t>(B + 4);
+    c->d_step = k.take<int32_t>(4);
+    c->d_next = k.take<int32_t>(B);
+    c->d_fin = k.take<int32_t>(B);
+    c->d_nunf = k.take<int32_t>((size_t)g.max_new_tokens + 4);
+    c->d_eos = k.take<int32_t>(64);
+    c->d_plan = k.take<int32_t>(4 * B + 8);
+    *total = k.off;
+}
+
+static int check_cfg(const opus_config *g) {
+    if (!g) return fail(OPUS_EBADARG, "config is null");
+    if (g->enc_layers < 1 || g->dec_layers < 1 || g->enc_heads < 1 || g->dec_heads < 1 || g->dec_kv_heads < 1)
+        return fail(OPUS_EBADARG, "layer/head counts must be positive");
+    if (g->enc_dim % g->enc_heads) return fail(OPUS_ESHAPE, "enc_dim %% enc_heads != 0");
+    const int ehd = g->enc_dim / g->enc_heads;
+    auto okhd = [](int h) { return h == 16 || h == 32 || h == 64 || h == 128; };
+    if (!okhd(ehd) || !okhd(g->dec_head_dim)) return fail(OPUS_ESHAPE, "head_dim must be 16/32/64/128");
+    if (g->dec_heads % g->dec_kv_heads || g->dec_heads / g->dec_kv_heads > 8)
+        return fail(OPUS_ESHAPE, "dec_heads / dec_kv_heads must be an integer <= 8");
+    const int ks[] = {g->enc_dim, g->enc_ffn, g->dec_dim, g->dec_ffn, g->dec_heads * g->dec_head_dim,
+                      g->has_protein_projector ? g->proj_dim : 64, g->dec_dim * g->n_prot_tokens};
+    for (int k : ks)
+        if (k % 64) return fail(OPUS_ESHAPE, "every GEMM reduction dim must be a multiple of 64 (got %d)", k);
+    if (g->enc_dim > 5120 || g->dec_dim > 5120) return fail(OPUS_ESHAPE, "norm width > 5120 unsupported");
+    if (g->switch_depth < 1 || g->n_prot_tokens < 1) return fail(OPUS_EBADARG, "switch_depth/n_prot_tokens");
+    if (g->max_batch < 1 || g->max_enc_tokens < 3 || g->max_prompt < 1 || g->max_new_tokens < 1)
+        return fail(OPUS_EBADARG, "capacity fields must be positive");
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int opus_abi_version(void) { return OPUS_ABI_VERSION; }
+extern "C" const char *opus_last_error(void) { return g_err; }
+
+extern "C" int64_t opus_workspace_bytes(const opus_config *cfg) {
+    if (check_cfg(cfg) != OPUS_OK) return -1;
+    opus_ctx tmp;
+    tmp.cfg = *cfg;
+    size_t total = 0;
+    carve(&tmp, nullptr, &total);
+    return (int64_t)total;
+}
+
+static void fill_cs(std::vector<float> &t, int maxpos, int hd, float theta) {
+    const int half = hd / 2;
+    t.resize((size_t)maxpos * half * 2);
+    for (int i = 0; i < half; ++i) {
+        // fp32 inv_freq as torch computes it, angle evaluated in double
+        const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)hd);
+        for (int p = 0; p < maxpos; ++p) {
+            const float ang = (float)p * inv;
+            t[((size_t)p * half + i) * 2] = (float)cos((double)ang);
+            t[((size_t)p * half + i) * 2 + 1] = (float)sin((double)ang);
+        }
+    }
+}
+
+extern "C" int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **out) {
+    if (!out) return fail(OPUS_EBADARG, "out is null");
+    OPC(check_cfg(cfg));
+    HIPC(hipSetDevice(device));
+    opus_ctx *c = new opus_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    size_t total = 0;
+    carve(c, nullptr, &total);
+    hipError_t e = hipMalloc((void **)&c->ws, total);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(OPUS_EHIP, "hipMalloc(%zu bytes of workspace) failed: %s", total, hipGetErrorString(e));
+    }
+    c->ws_bytes = total;
+    carve(c, c->ws, &total);
+    std::vector<float> t;
+    fill_cs(t, cfg->max_enc_tokens, cfg->enc_dim / cfg->enc_heads, cfg->enc_rope_theta);
+    HIPC(hipMemcpy(c->cs_enc, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    fill_cs(t, cfg->max_prompt + cfg->max_new_tokens, cfg->dec_head_dim, cfg->dec_rope_theta);
+    HIPC(hipMemcpy(c->cs_dec, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPC(hipMemset(c->d_step, 0, 16));
+    *out = c;
+    return OPUS_OK;
+}
+
+static void timing_clear(opus_ctx *c) {
+    for (auto &r : c->recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    c->recs.clear();
+}
+
+extern "C" int opus_ctx_destroy(opus_ctx *c) {
+    if (!c) return OPUS_OK;
+    (void)hipSetDevice(c->device);
+    timing_clear(c);
+    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    if (c->ws) (void)hipFree(c->ws);
+    delete c;
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+extern "C" int opus_bind_weight(opus_ctx *c, const char *name, const void *d_ptr, int dtype, int ndim,
+                                const int64_t *shape) {
+    if (!c || !name || !d_ptr || !shape) return fail(OPUS_EBADARG, "null argument");
+    if (ndim < 1 || ndim > 4) return fail(OPUS_EBADARG, "ndim %d", ndim);
+    if (dtype != OPUS_F16 && dtype != OPUS_F32) return fail(OPUS_EBADARG, "weights are fp16 or fp32");
+    if (((uintptr_t)d_ptr) & 15) return fail(OPUS_EBADARG, "%s: pointer must be 16-byte aligned", name);
+    Tensor t;
+    t.p = d_ptr;
+    t.dtype = dtype;
+    t.shape.assign(shape, shape + ndim);
+    c->w[name] = t;
+    c->resolved = false;
+    return OPUS_OK;
+}
+
+static int getw(opus_ctx *c, const std::string &name, int dtype, std::vector<int64_t> shape, const void **out) {
+    auto it = c->w.find(name);
+    if (it == c->w.end()) return fail(OPUS_ESTATE, "weight '%s' is not bound", name.c_str());
+    const Tensor &t = it->second;
+    if (t.dtype != dtype) return fail(OPUS_ESHAPE, "weight '%s' has dtype %d, expected %d", name.c_str(), t.dtype, dtype);
+    if (t.shape != shape) {
+        std::string got, exp;
+        for (auto v : t.shape) got += std::to_string(v) + ",";
+        for (auto v : shape) exp += std::to_string(v) + ",";
+        return fail(OPUS_ESHAPE, "weight '%s' has shape [%s] expected [%s]", name.c_str(), got.c_str(), exp.c_str());
+    }
+    *out = t.p;
+    return OPUS_OK;
+}
+#define GW(name, dt, shape, dst) OPC(getw(c, name, dt, shape, reinterpret_cast<const void **>(&(dst))))
+
+extern "C" int opus_weights_ready(opus_ctx *c) {
+    if (!c) return fail(OPUS_EBADARG, "ctx is null");
+    if (c->resolved) return OPUS_OK;
+    const opus_config &g = c->cfg;
+    const int64_t De = g.enc_dim, Fe = g.enc_ffn, H = g.dec_dim, F = g.dec_ffn, V = g.dec_vocab;
+    const int64_t QKV = (int64_t)(g.dec_heads + 2 * g.dec_kv_heads) * g.dec_head_dim, QD = (int64_t)g.dec_heads * g.dec_head_dim;
+    GW("enc.emb", OPUS_F16, (std::vector<int64_t>{g.enc_vocab, De}), c->enc_emb);
+    c->enc.resize(g.enc_layers);
+    for (int l = 0; l < g.enc_layers; ++l) {
+        const std::string p = "enc." + std::to_string(l) + ".";
+        EncLayer &L = c->enc[l];
+        GW(p + "ln1.w", OPUS_F32, (std::vector<int64_t>{De}), L.ln1w);
+        GW(p + "ln1.b", OPUS_F32, (std::vector<int64_t>{De}), L.ln1b);
+        GW(p + "wqkv", OPUS_F16, (std::vector<int64_t>{3 * De, De}), L.wqkv);
+        GW(p + "bqkv", OPUS_F32, (std::vector<int64_t>{3 * De}), L.bqkv);
+        GW(p + "wo", OPUS_F16, (std::vector<int64_t>{De, De}), L.wo);
+        GW(p + "bo", OPUS_F32, (std::vector<int64_t>{De}), L.bo);
+        GW(p + "ln2.w", OPUS_F32, (std::vector<int64_t>{De}), L.ln2w);
+        GW(p + "ln2.b", OPUS_F32, (std::vector<int64_t>{De}), L.ln2b);
+        GW(p + "w1", OPUS_F16, (std::vector<int64_t>{Fe, De}), L.w1);
+        GW(p + "b1", OPUS_F32, (std::vector<int64_t>{Fe}), L.b1);
+        GW(p + "w2", OPUS_F16, (std::vector<int64_t>{De, Fe}), L.w2);
+        GW(p + "b2", OPUS_F32, (std::vector<int64_t>{De}), L.b2);
+    }
+    GW("enc.lnf.w", OPUS_F32, (std::vector<int64_t>{De}), c->enc_lnfw);
+    GW("enc.lnf.b", OPUS_F32, (std::vector<int64_t>{De}), c->enc_lnfb);
+    int64_t din = De;
+    if (g.has_protein_projector) {
+        GW("proj.w", OPUS_F16, (std::vector<int64_t>{g.proj_dim, De}), c->proj_w);
+        GW("proj.b", OPUS_F32, (std::vector<int64_t>{g.proj_dim}), c->proj_b);
+        din = g.proj_dim;
+    }
+    const int64_t SW = H * g.n_prot_tokens;
+    c->sw_w.resize(g.switch_depth);
+    c->sw_b.resize(g.switch_depth);
+    for (int i = 0; i < g.switch_depth; ++i) {
+        const std::string p = "sw." + std::to_string(i) + ".";
+        GW(p + "w", OPUS_F16, (std::vector<int64_t>{SW, din}), c->sw_w[i]);
+        GW(p + "b", OPUS_F32, (std::vector<int64_t>{SW}), c->sw_b[i]);
+        din = SW;
+    }
+    GW("dec.emb", OPUS_F16, (std::vector<int64_t>{V, H}), c->dec_emb);
+    c->dec.resize(g.dec_layers);
+    for (int l = 0; l < g.dec_layers; ++l) {
+        const std::string p = "dec." + std::to_string(l) + ".";
+        DecLayer &L = c->dec[l];
+        GW(p + "ln1", OPUS_F32, (std::vector<int64_t>{H}), L.ln1);
+        GW(p + "wqkv", OPUS_F16, (std::vector<int64_t>{QKV, H}), L.wqkv);
+        GW(p + "wo", OPUS_F16, (std::vector<int64_t>{H, QD}), L.wo);
+        GW(p + "ln2", OPUS_F32, (std::vector<int64_t>{H}), L.ln2);
+        GW(p + "wgu", OPUS_F16, (std::vector<int64_t>{2 * F, H}), L.wgu);
+        GW(p + "wd", OPUS_F16, (std::vector<int64_t>{H, F}), L.wd);
+    }
+    GW("dec.lnf", OPUS_F32, (std::vector<int64_t>{H}), c->dec_lnf);
+    GW("dec.lm_head", OPUS_F16, (std::vector<int64_t>{V, H}), c->lm_head);
+    c->resolved = true;
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+struct Timed {
+    opus_ctx *c;
+    hipStream_t s;
+    int klass;
+    double bytes;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timed(opus_ctx *c_, hipStream_t s_, int k, double b) : c(c_), s(s_), klass(k), bytes(b) {
+        if (c->timing) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, s);
+        }
+    }
+    ~Timed() {
+        if (c->timing) {
+            (void)hipEventRecord(e1, s);
+            c->recs.push_back(TimeRec{klass, e0, e1, bytes});
+        }
+    }
+};
+
+static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const half_t *W, int M, int N, int K,
+                const float *bias, int epi, const float *residual, void *C, int64_t ldc, int out_f32) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias; p.residual = residual;
+    p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
+    const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
+    const double bytes = 2.0 * N * K + 2.0 * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
+                         (residual ? 4.0 * M * nout : 0.0);
+    int klass = M <= 64 ? KC_SKINNY : KC_TILE;
+    Timed t(c, s, klass, bytes);
+    hipError_t e = launch_gemm(p, s, &klass);
+    if (e != hipSuccess) return fail(OPUS_EHIP, "gemm M=%d N=%d K=%d failed: %s", M, N, K, hipGetErrorString(e));
+    return OPUS_OK;
+}
+#define KL(klass, bytes, call)                                                                        \
+    do {                                                                                              \
+        Timed t_(c, s, klass, bytes);                                                                 \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(OPUS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static int need_ready(opus_ctx *c) {
+    if (!c) return fail(OPUS_EBADARG, "ctx is null");
+    OPC(opus_weights_ready(c));
+    HIPC(hipSetDevice(c->device));
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ load-time ops
+extern "C" int opus_lora_merge(void *W, const void *A, const void *B, float scale, int64_t out_f, int64_t in_f,
+                               int32_t r, void *stream) {
+    if (!W || !A || !B || out_f < 1 || in_f < 1 || r < 1) return fail(OPUS_EBADARG, "lora_merge: bad argument");
+    if (in_f % 8) return fail(OPUS_ESHAPE, "lora_merge: in_features must be a multiple of 8");
+    HIPC(launch_lora_merge((half_t *)W, (const half_t *)A, (const half_t *)B, scale, out_f, in_f, r, (hipStream_t)stream));
+    return OPUS_OK;
+}
+
+extern "C" int opus_fill_synth(void *dst, int dtype, int64_t rows, int64_t cols, uint64_t seed, float std, float mean,
+                               int64_t row_block, int64_t row_stride, int64_t row_off, void *stream) {
+    if (!dst || rows < 1 || cols < 1 || (dtype != OPUS_F16 && dtype != OPUS_F32) || row_block < 1 || row_stride < row_block)
+        return fail(OPUS_EBADARG, "fill_synth: bad argument");
+    HIPC(launch_fill_synth(dst, dtype, rows, cols, seed, std, mean, row_block, row_stride, row_off, (hipStream_t)stream));
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ encoder
+extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int32_t *d_lens, int32_t B, int32_t T,
+                                float *d_pooled, void *stream) {
+    OPC(need_ready(c));
+    if (!d_tokens || !d_lens || !d_pooled) return fail(OPUS_EBADARG, "esm2_encode: null pointer");
+    const opus_config &g = c->cfg;
+    if (B < 1 || B > g.max_batch || T < 3 || T > g.max_enc_tokens)
+        return fail(OPUS_ESHAPE, "esm2_encode: B=%d T=%d exceed capacity (%d, %d)", B, T, g.max_batch, g.max_enc_tokens);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = g.enc_dim, F = g.enc_ffn, nh = g.enc_heads, hd = D / nh;
+    const int M = B * T;
+    KL(KC_OTHER, 4.0 * M * D, launch_esm_embed(d_tokens, c->enc_emb, B, T, D, c->e_x, s));
+    for (int l = 0; l < g.enc_layers; ++l) {
+        const EncLayer &L = c->enc[l];
+        KL(KC_OTHER, 6.0 * M * D, launch_layernorm(c->e_x, L.ln1w, L.ln1b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
+        OPC(gemm(c, s, c->e_xn, D, L.wqkv, M, 3 * D, D, L.bqkv, EPI_NONE, nullptr, c->e_qkv, 3 * D, 0));
+        KL(KC_OTHER, 8.0 * M * D, launch_esm_rope(c->e_qkv, c->cs_enc, B, T, nh, hd, 1.0f / sqrtf((float)hd), s));
+        AttnParams a;
+        a.Q = c->e_qkv; a.K = c->e_qkv + D; a.V = c->e_qkv + 2 * D;
+        a.q_sb = a.k_sb = a.v_sb = (int64_t)T * 3 * D;
+        a.q_st = a.k_st = a.v_st = 3 * D;
+        a.O = c->e_ctx; a.o_sb = (int64_t)T * D; a.o_st = D;
+        a.kstart = nullptr; a.kend = d_lens;
+        a.B = B; a.T = T; a.heads = nh; a.group = 1; a.head_dim = hd; a.causal = 0; a.scale = 1.0f;
+        KL(KC_ATTN_PREFILL, 8.0 * M * D, launch_attn_prefill(a, s));
+        OPC(gemm(c, s, c->e_ctx, D, L.wo, M, D, D, L.bo, EPI_NONE, c->e_x, c->e_x, D, 1));
+        KL(KC_OTHER, 6.0 * M * D, launch_layernorm(c->e_x, L.ln2w, L.ln2b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
+        OPC(gemm(c, s, c->e_xn, D, L.w1, M, F, D, L.b1, EPI_GELU, nullptr, c->e_h1, F, 0));
+        OPC(gemm(c, s, c->e_h1, F, L.w2, M, D, F, L.b2, EPI_NONE, c->e_x, c->e_x, D, 1));
+    }
+    KL(KC_OTHER, 8.0 * M * D, launch_layernorm(c->e_x, c->enc_lnfw, c->enc_lnfb, g.enc_ln_eps, M, D, nullptr, c->e_hid, s));
+    KL(KC_OTHER, 4.0 * M * D, launch_masked_mean(c->e_hid, d_lens, B, T, D, d_pooled, s));
+    return OPUS_OK;
+}
+
+extern "C" int opus_esm2_last_hidden(opus_ctx *c, float *d_out, int32_t B, int32_t T, void *stream) {
+    if (!c || !d_out) return fail(OPUS_EBADARG, "null pointer");
+    if (B < 1 || B > c->cfg.max_batch || T < 1 || T > c->cfg.max_enc_tokens) return fail(OPUS_ESHAPE, "B/T out of range");
+    HIPC(hipMemcpyAsync(d_out, c->e_hid, (size_t)B * T * c->cfg.enc_dim * sizeof(float), hipMemcpyDeviceToDevice,
+                        (hipStream_t)stream));
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ projectors
+extern "C" int opus_protein_projector(opus_ctx *c, const float *d_pooled, int32_t B, void *d_out, void *stream) {
+    OPC(need_ready(c));
+    if (!d_pooled || !d_out) return fail(OPUS_EBADARG, "protein_projector: null pointer");
+    const opus_config &g = c->cfg;
+    if (B < 1 || B > g.max_batch) return fail(OPUS_ESHAPE, "protein_projector: B=%d exceeds max_batch=%d", B, g.max_batch);
+    if (!g.has_protein_projector)
+        return fail(OPUS_EUNSUPPORTED, "has_protein_projector = 0 (identity projector, opus_arch.py:70-80) is not built");
+    hipStream_t s = (hipStream_t)stream;
+    const int De = g.enc_dim;
+    KL(KC_OTHER, 6.0 * B * De, launch_l2norm(d_pooled, B, De, c->p_xn, s));
+    return gemm(c, s, c->p_xn, De, c->proj_w, B, g.proj_dim, De, c->proj_b, EPI_NONE, nullptr, d_out, g.proj_dim, 0);
+}
+
+extern "C" int opus_switch_projector(opus_ctx *c, const void *d_in, int32_t B, void *d_out, void *stream) {
+    OPC(need_ready(c));
+    if (!d_in || !d_out) return fail(OPUS_EBADARG, "switch_projector: null pointer");
+    const opus_config &g = c->cfg;
+    if (B < 1 || B > g.max_batch) return fail(OPUS_ESHAPE, "switch_projector: B=%d exceeds max_batch=%d", B, g.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int SW = g.dec_dim * g.n_prot_tokens;
+    int din = g.has_protein_projector ? g.proj_dim : g.enc_dim;
+    const half_t *in = (const half_t *)d_in;
+    for (int i = 0; i < g.switch_depth; ++i) {
+        const bool last = i + 1 == g.switch_depth;
+        half_t *o = last ? (half_t *)d_out : c->p_z[i & 1];
+        // nn.GELU() sits between the Linear layers (protein_mlp/builder.py:21-24): fused as the epilogue
+        OPC(gemm(c, s, in, din, c->sw_w[i], B, SW, din, c->sw_b[i], last ? EPI_NONE : EPI_GELU, nullptr, o, SW, 0));
+        in = o;
+        din = SW;
+    }
+    return OPUS_OK;
+}
+
+extern "C" int opus_projector_forward(opus_ctx *c, const float *d_pooled, int32_t B, void *d_out, void *d_proj_out,
+                                      void *stream) {
+    if (!c) return fail(OPUS_EBADARG, "ctx is null");
+    OPC(opus_protein_projector(c, d_pooled, B, c->p_y, stream));
+    if (d_proj_out)
+        HIPC(hipMemcpyAsync(d_proj_out, c->p_y, (size_t)B * c->cfg.proj_dim * sizeof(half_t), hipMemcpyDeviceToDevice,
+                            (hipStream_t)stream));
+    return opus_switch_projector(c, c->p_y, B, d_out, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ splice
+extern "C" int opus_splice_pad(opus_ctx *c, const int64_t *d_ids, const uint8_t *d_mask, int32_t B, int32_t Tt,
+                               const void *d_prot, int32_t n_prot, int32_t inference_mode, int32_t max_length,
+                               void *d_embeds, uint8_t *d_mask_out, int32_t *d_pos_out, int32_t *T_out, void *stream) {
+    OPC(need_ready(c));
+    if (!d_ids || !d_prot || !d_embeds || !d_mask_out || !d_pos_out || !T_out) return fail(OPUS_EBADARG, "splice_pad: null pointer");
+    const opus_config &g = c->cfg;
+    if (B < 1 || B > g.max_batch || Tt < 1) return fail(OPUS_ESHAPE, "splice_pad: B=%d T_text=%d out of range", B, Tt);
+    hipStream_t s = (hipStream_t)stream;
+    KL(KC_OTHER, 9.0 * B * Tt, launch_splice_plan(d_ids, d_mask, B, Tt, g.n_prot_tokens, max_length, g.dec_vocab, c->d_plan, s));
+    int32_t tail[3];
+    HIPC(hipMemcpyAsync(tail, c->d_plan + 4 * B, sizeof(tail), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    if (tail[2]) return fail(OPUS_EBADARG, "splice_pad: token id outside [0, vocab) (and not -200)");
+    if (tail[1] > n_prot) return fail(OPUS_ESHAPE, "splice_pad: rows consume %d protein blocks, %d supplied", tail[1], n_prot);
+    if (tail[0] > g.max_prompt) return fail(OPUS_ESHAPE, "splice_pad: spliced length %d exceeds max_prompt=%d", tail[0], g.max_prompt);
+    if (tail[0] < 1) return fail(OPUS_ESHAPE, "splice_pad: every row is empty");
+    *T_out = tail[0];
+    KL(KC_OTHER, 2.0 * B * tail[0] * g.dec_dim * 2,
+       launch_splice_fill(d_ids, d_mask, B, Tt, (const half_t *)d_prot, g.n_prot_tokens, g.dec_dim, g.dec_vocab, c->dec_emb,
+                          c->d_plan, tail[0], inference_mode ? 1 : 0, (half_t *)d_embeds, d_mask_out, d_pos_out, s));
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+static int lm_head(opus_ctx *c, hipStream_t s, int B) {
+    const opus_config &g = c->cfg;
+    KL(KC_OTHER, 6.0 * B * g.dec_dim, launch_rmsnorm(c->d_xl, c->dec_lnf, g.dec_rms_eps, B, g.dec_dim, c->d_xln, s));
+    return gemm(c, s, c->d_xln, g.dec_dim, c->lm_head, B, g.dec_vocab, g.dec_dim, nullptr, EPI_NONE, nullptr, c->d_logits,
+                g.dec_vocab, 1);
+}
+
+static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8_t *mask, int B, int T) {
+    const opus_config &g = c->cfg;
+    const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
+    const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
+    const int M = B * T;
+    KL(KC_OTHER, 1.0 * M, launch_mask_to_kstart(mask, B, T, c->d_kstart, s));
+    KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
+    for (int l = 0; l < g.dec_layers; ++l) {
+        const DecLayer &L = c->dec[l];
+        KL(KC_OTHER, 6.0 * M * H, launch_rmsnorm(c->d_x, L.ln1, g.dec_rms_eps, M, H, c->d_xn, s));
+        OPC(gemm(c, s, c->d_xn, H, L.wqkv, M, QKV, H, nullptr, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
+        KL(KC_OTHER, 4.0 * M * QKV,
+           launch_dec_rope_cache(c->d_qkv, c->cs_dec, c->d_kstart, B, T, nh, nkv, hd, c->kc + l * c->cache_sl,
+                                 c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, s));
+        AttnParams a;
+        a.Q = c->d_qkv; a.K = c->d_qkv + QD; a.V = c->d_qkv + QD + nkv * hd;
+        a.q_sb = a.k_sb = a.v_sb = (int64_t)T * QKV;
+        a.q_st = a.k_st = a.v_st = QKV;
+        a.O = c->d_ctx; a.o_sb = (int64_t)T * QD; a.o_st = QD;
+        a.kstart = c->d_kstart; a.kend = nullptr;
+        a.B = B; a.T = T; a.heads = nh; a.group = nh / nkv; a.head_dim = hd; a.causal = 1;
+        a.scale = 1.0f / sqrtf((float)hd);
+        KL(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), launch_attn_prefill(a, s));
+        OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
+        KL(KC_OTHER, 6.0 * M * H, launch_rmsnorm(c->d_x, L.ln2, g.dec_rms_eps, M, H, c->d_xn, s));
+        OPC(gemm(c, s, c->d_xn, H, L.wgu, M, 2 * F, H, nullptr, EPI_SILU_GU16, nullptr, c->d_act, F, 0));
+        OPC(gemm(c, s, c->d_act, F, L.wd, M, H, F, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
+    }
+    KL(KC_OTHER, 8.0 * B * H, launch_take_last(c->d_x, B, T, H, c->d_xl, s));
+    OPC(lm_head(c, s, B));
+    HIPC(hipMemsetAsync(c->d_step, 0, sizeof(int32_t), s));
+    c->cur_B = B;
+    c->cur_T = T;
+    c->prefilled = true;
+    return OPUS_OK;
+}
+
+// One decode step for the token ids in d_tok (device): embeds them, runs the stack at slot T + *step,
+// leaves logits in c->d_logits and advances *step.
+static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
+    const opus_config &g = c->cfg;
+    const int B = c->cur_B, T = c->cur_T;
+    const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
+    const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
+    const int ctx_cap = g.max_prompt + g.max_new_tokens;
+    KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, s));
+    for (int l = 0; l < g.dec_layers; ++l) {
+        const DecLayer &L = c->dec[l];
+        KL(KC_OTHER, 6.0 * B * H, launch_rmsnorm(c->d_xl, L.ln1, g.dec_rms_eps, B, H, c->d_xln, s));
+        OPC(gemm(c, s, c->d_xln, H, L.wqkv, B, QKV, H, nullptr, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
+        KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (T + 1),
+           launch_attn_decode(c->d_qkv, c->cs_dec, c->d_kstart, c->d_step, T, B, nh, nkv, hd, c->kc + l * c->cache_sl,
+                              c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, ctx_cap, 1.0f / sqrtf((float)hd),
+                              c->d_ctx, s));
+        OPC(gemm(c, s, c->d_ctx, QD, L.wo, B, H, QD, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
+        KL(KC_OTHER, 6.0 * B * H, launch_rmsnorm(c->d_xl, L.ln2, g.dec_rms_eps, B, H, c->d_xln, s));
+        OPC(gemm(c, s, c->d_xln, H, L.wgu, B, 2 * F, H, nullptr, EPI_SILU_GU16, nullptr, c->d_act, F, 0));
+        OPC(gemm(c, s, c->d_act, F, L.wd, B, H, F, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
+    }
+    OPC(lm_head(c, s, B));
+    KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
+    return OPUS_OK;
+}
+
+static int check_prefill_args(opus_ctx *c, const void *e, const uint8_t *m, int B, int T) {
+    if (!e || !m) return fail(OPUS_EBADARG, "prefill: null pointer");
+    if (B < 1 || B > c->cfg.max_batch || T < 1 || T > c->cfg.max_prompt)
+        return fail(OPUS_ESHAPE, "prefill: B=%d T=%d exceed capacity (%d, %d)", B, T, c->cfg.max_batch, c->cfg.max_prompt);
+    return OPUS_OK;
+}
+
+extern "C" int opus_llama_prefill(opus_ctx *c, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
+                                  float *d_last_logits, void *stream) {
+    OPC(need_ready(c));
+    OPC(check_prefill_args(c, d_embeds, d_mask, B, T));
+    hipStream_t s = (hipStream_t)stream;
+    OPC(prefill(c, s, (const half_t *)d_embeds, d_mask, B, T));
+    if (d_last_logits)
+        HIPC(hipMemcpyAsync(d_last_logits, c->d_logits, (size_t)B * c->cfg.dec_vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return OPUS_OK;
+}
+
+extern "C" int opus_llama_decode_step(opus_ctx *c, const int32_t *d_tok, float *d_logits, void *stream) {
+    OPC(need_ready(c));
+    if (!c->prefilled) return fail(OPUS_ESTATE, "decode_step before prefill");
+    if (!d_tok) return fail(OPUS_EBADARG, "decode_step: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t st = 0;
+    HIPC(hipMemcpyAsync(&st, c->d_step, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    if (st >= c->cfg.max_new_tokens) return fail(OPUS_ESHAPE, "decode_step: KV cache is full (%d steps)", st);
+    OPC(decode_step(c, s, d_tok));
+    if (d_logits)
+        HIPC(hipMemcpyAsync(d_logits, c->d_logits, (size_t)c->cur_B * c->cfg.dec_vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return OPUS_OK;
+}
+
+// iteration body of the greedy loop: pick the next token from the current logits, then decode it.
+static int greedy_body(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id, int32_t *d_out) {
+    const opus_config &g = c->cfg;
+    KL(KC_OTHER, 4.0 * c->cur_B * g.dec_vocab,
+       launch_argmax_step(c->d_logits, c->cur_B, g.dec_vocab, c->d_eos, n_eos, pad_id, c->d_fin, d_out, max_new, c->d_step,
+                          c->d_next, c->d_nunf, s));
+    return decode_step(c, s, c->d_next);
+}
+
+extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
+                                    int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id,
+                                    int32_t *d_out_ids, int32_t *n_out, void *stream) {
+    OPC(need_ready(c));
+    OPC(check_prefill_args(c, d_embeds, d_mask, B, T));
+    if (!d_out_ids || !n_out) return fail(OPUS_EBADARG, "generate_greedy: null pointer");
+    if (max_new < 1 || max_new > c->cfg.max_new_tokens)
+        return fail(OPUS_ESHAPE, "generate_greedy: max_new=%d exceeds max_new_tokens=%d", max_new, c->cfg.max_new_tokens);
+    if (n_eos < 0 || n_eos > 64 || (n_eos > 0 && !eos_ids)) return fail(OPUS_EBADARG, "generate_greedy: eos list");
+    hipStream_t s = (hipStream_t)stream;
+    const opus_config &g = c->cfg;
+    if (n_eos) HIPC(hipMemcpyAsync(c->d_eos, eos_ids, n_eos * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPC(hipMemsetAsync(c->d_fin, 0, B * sizeof(int32_t), s));
+    HIPC(hipMemsetAsync(c->d_nunf, 0, (size_t)max_new * sizeof(int32_t), s));
+    OPC(prefill(c, s, (const half_t *)d_embeds, d_mask, B, T));
+
+    const bool use_graph = s != nullptr && !c->timing;
+    auto graph_matches = [&]() {
+        return c->gexec && c->g_B == B && c->g_T == T && c->g_maxnew == max_new && c->g_pad == pad_id &&
+               c->g_neos == n_eos && c->g_out == d_out_ids;
+    };
+    const bool same_graph = graph_matches();
+    std::vector<int32_t> nunf(max_new, 1);
+    int produced = 0;
+    for (int i = 0; i < max_new; ++i) {
+        if (i + 1 == max_new) {   // last token: no decode behind it
+            KL(KC_OTHER, 4.0 * B * g.dec_vocab,
+               launch_argmax_step(c->d_logits, B, g.dec_vocab, c->d_eos, n_eos, pad_id, c->d_fin, d_out_ids, max_new,
+                                  c->d_step, c->d_next, c->d_nunf, s));
+            produced = i + 1;
+            break;
+        }
+        if (!use_graph || (i == 0 && !same_graph)) {
+            OPC(greedy_body(c, s, max_new, n_eos, pad_id, d_out_ids));   // eager (also warms lazily-set attributes)
+        } else {
+            if (!graph_matches()) {
+                if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+                hipGraph_t graph = nullptr;
+                HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                int rc = greedy_body(c, s, max_new, n_eos, pad_id, d_out_ids);
+                hipError_t ee = hipStreamEndCapture(s, &graph);
+                if (rc != OPUS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                if (ee != hipSuccess) return fail(OPUS_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ee));
+                ee = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ee != hipSuccess) { c->gexec = nullptr; return fail(OPUS_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ee)); }
+                c->g_B = B; c->g_T = T; c->g_maxnew = max_new; c->g_pad = pad_id; c->g_neos = n_eos;
+                c->g_out = d_out_ids;
+            }
+            HIPC(hipGraphLaunch(c->gexec, s));
+        }
+        produced = i + 1;
+        // HF stops as soon as every row has finished; poll every 8 steps (finished rows emit pad, so
+        // the ids are identical and n_out is computed exactly below).
+        if (n_eos > 0 && (i & 7) == 7) {
+            HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)(i + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIPC(hipStreamSynchronize(s));
+            bool done = false;
+            for (int k = 0; k <= i; ++k) if (nunf[k] == 0) { done = true; break; }
+            if (done) break;
+        }
+    }
+    HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)produced * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    int n = produced;
+    for (int k = 0; k < produced; ++k) if (nunf[k] == 0) { n = k + 1; break; }
+    *n_out = n;
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+extern "C" int opus_debug_gemm(opus_ctx *c, const void *A, const void *W, const float *bias, const float *residual,
+                               void *Cp, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t out_f32, void *stream) {
+    if (!c || !A || !W || !Cp) return fail(OPUS_EBADARG, "debug_gemm: null pointer");
+    if (M < 1 || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm: K must be a positive multiple of 64");
+    if (epi < 0 || epi > 2 || (epi == 2 && N % 32)) return fail(OPUS_EBADARG, "debug_gemm: epilogue");
+    HIPC(hipSetDevice(c->device));
+    const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
+    return gemm(c, (hipStream_t)stream, (const half_t *)A, K, (const half_t *)W, M, N, K, bias, epi, residual, Cp, nout,
+                out_f32);
+}
+
+extern "C" int opus_debug_attention(opus_ctx *c, const void *Q, const void *K, const void *V, void *O,
+                                    const int32_t *kstart, const int32_t *kend, int32_t B, int32_t T, int32_t heads,
+                                    int32_t group, int32_t hd, int32_t causal, float scale, void *stream) {
+    if (!c || !Q || !K || !V || !O) return fail(OPUS_EBADARG, "debug_attention: null pointer");
+    if (B < 1 || T < 1 || heads < 1 || group < 1 || heads % group) return fail(OPUS_ESHAPE, "debug_attention: shape");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    AttnParams a;
+    const int kvh = heads / group;
+    a.Q = (const half_t *)Q; a.K = (const half_t *)K; a.V = (const half_t *)V; a.O = (half_t *)O;
+    a.q_st = (int64_t)heads * hd; a.q_sb = a.q_st * T;
+    a.k_st = a.v_st = (int64_t)kvh * hd; a.k_sb = a.v_sb = a.k_st * T;
+    a.o_st = a.q_st; a.o_sb = a.q_sb;
+    a.kstart = kstart; a.kend = kend; a.B = B; a.T = T; a.heads = heads; a.group = group; a.head_dim = hd;
+    a.causal = causal; a.scale = scale;
+    KL(KC_ATTN_PREFILL, 2.0 * B * T * hd * (2.0 * heads + 2.0 * kvh), launch_attn_prefill(a, s));
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ timing
+extern "C" int opus_timing_enable(opus_ctx *c, int32_t on) {
+    if (!c) return fail(OPUS_EBADARG, "ctx is null");
+    c->timing = on != 0;
+    return OPUS_OK;
+}
+extern "C" int opus_timing_reset(opus_ctx *c) {
+    if (!c) return fail(OPUS_EBADARG, "ctx is null");
+    HIPC(hipDeviceSynchronize());
+    timing_clear(c);
+    return OPUS_OK;
+}
+extern "C" int opus_timing_get(opus_ctx *c, const char *kernel_class, double *ms, int64_t *launches, double *bytes) {
+    if (!c || !kernel_class || !ms || !launches || !bytes) return fail(OPUS_EBADARG, "null argument");
+    static const char *names[KC_COUNT] = {"skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other"};
+    int k = -1;
+    for (int i = 0; i < KC_COUNT; ++i) if (!strcmp(names[i], kernel_class)) k = i;
+    if (k < 0) return fail(OPUS_EBADARG, "unknown kernel class '%s'", kernel_class);
+    HIPC(hipDeviceSynchronize());
+    double t = 0, b = 0;
+    int64_t n = 0;
+    for (auto &r : c->recs) {
+        if (r.klass != k) continue;
+        float e = 0;
+        HIPC(hipEventElapsedTime(&e, r.e0, r.e1));
+        t += e;
+        b += r.bytes;
+        ++n;
+    }
+    *ms = t;
+    *launches = n;
+    *bytes = b;
+    return OPUS_OK;
+}

@@ -1,0 +1,91 @@
+// Shared declarations for libopus_pllm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace opus {
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
+enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_COUNT = 5 };
+
+// C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.
+// EPI_SILU_GU16: W rows come in 32-row groups [16 gate | 16 up]; Nout = N/2, out = silu(g) * u.
+struct GemmParams {
+    const half_t *A;
+    int64_t lda;
+    const half_t *W;        // row-major [N,K]
+    int M, N, K;
+    const float *bias;      // [N] or nullptr
+    const float *residual;  // fp32 [M,Nout] or nullptr (may alias C when C is fp32)
+    int64_t ldr;
+    void *C;
+    int64_t ldc;
+    int out_f32;            // 1: C is fp32, 0: fp16
+    int epi;
+};
+
+// Flash-style attention over strided Q/K/V (fp16).  Q(b,h,t,:) = Q + b*q_sb + t*q_st + h*HD etc.;
+// kv head of q head h is h / group.  Key j of batch row b is visible to query i iff
+// kstart[b] <= j < kend[b] and (!causal || j <= i).  O is [B, T, heads*HD] row-major fp16.
+struct AttnParams {
+    const half_t *Q, *K, *V;
+    int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st;
+    half_t *O;
+    int64_t o_sb, o_st;
+    const int32_t *kstart;  // [B] or nullptr (= 0)
+    const int32_t *kend;    // [B] or nullptr (= T)
+    int B, T, heads, group, head_dim, causal;
+    float scale;
+};
+
+hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass);
+hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s);
+
+// norm.hip
+hipError_t launch_layernorm(const float *x, const float *w, const float *b, float eps, int64_t rows, int D,
+                            half_t *out_h, float *out_f, hipStream_t s);
+hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t rows, int D, half_t *out,
+                          hipStream_t s);
+hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s);
+hipError_t launch_masked_mean(const float *h, const int32_t *lens, int B, int T, int D, float *out,
+                              hipStream_t s);
+
+// elementwise.hip
+hipError_t launch_esm_embed(const int32_t *tok, const half_t *emb, int B, int T, int D, float *x, hipStream_t s);
+hipError_t launch_esm_rope(half_t *qkv, const float *cs, int B, int T, int heads, int hd, float qscale,
+                           hipStream_t s);
+hipError_t launch_dec_rope_cache(half_t *qkv, const float *cs, const int32_t *kstart, int B, int T, int nh,
+                                 int nkv, int hd, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh,
+                                 hipStream_t s);
+hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s);
+hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, hipStream_t s);
+hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s);
+hipError_t launch_fill_synth(void *dst, int dtype, int64_t rows, int64_t cols, uint64_t seed, float std,
+                             float mean, int64_t rb, int64_t rs, int64_t ro, hipStream_t s);
+hipError_t launch_lora_merge(half_t *W, const half_t *A, const half_t *B, float scale, int64_t out_f,
+                             int64_t in_f, int r, hipStream_t s);
+hipError_t launch_splice_plan(const int64_t *ids, const uint8_t *mask, int B, int Tt, int n_tok, int max_len,
+                              int V, int32_t *plan, hipStream_t s);
+hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, int Tt, const half_t *prot,
+                              int n_tok, int H, int V, const half_t *emb, const int32_t *plan, int Tout,
+                              int left_pad, half_t *out, uint8_t *mask_out, int32_t *pos_out, hipStream_t s);
+hipError_t launch_argmax_step(const float *logits, int B, int V, const int32_t *eos, int n_eos, int pad_id,
+                              int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
+                              int32_t *next_tok, int32_t *n_unfinished, hipStream_t s);
+hipError_t launch_step_advance(int32_t *step, hipStream_t s);
+hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kstart, hipStream_t s);
+
+// attn_decode.hip : rope(q,k at the new slot) + cache append + single-query attention
+hipError_t launch_attn_decode(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step,
+                              int T0, int B, int nh, int nkv, int hd, half_t *kc, half_t *vc, int64_t cache_sb,
+                              int64_t cache_sh, int ctx_cap, float scale, half_t *out, hipStream_t s);
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace opus

@@ -1,0 +1,405 @@
+// Memory-bound glue kernels of the path (gather / rotary / cache append / splice / argmax / fill).
+#include "common.h"
+
+namespace opus {
+
+// ------------------------------------------------------------------------------ ESM-2 embedding (E1)
+// x[b,t,:] = emb[tok] * 0.88 / (1 - n_mask_b / n_nonpad_b), <mask> rows and <pad> rows zeroed
+// (token-dropout rescale of fair_esm ESM2.forward; modeling_esm.py:252-268).
+__global__ __launch_bounds__(256) void esm_embed_kernel(const int32_t *__restrict__ tok, const half_t *__restrict__ emb,
+                                                        int T, int D, float *__restrict__ x) {
+    __shared__ int s_cnt[2];
+    const int b = blockIdx.y;
+    const int32_t *row = tok + (int64_t)b * T;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int nm = 0, nv = 0;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const int v = row[t];
+        nm += (v == 32);
+        nv += (v != 1);
+    }
+    atomicAdd(&s_cnt[0], nm);
+    atomicAdd(&s_cnt[1], nv);
+    __syncthreads();
+    const float scale = (1.0f - 0.15f * 0.8f) / (1.0f - (float)s_cnt[0] / (float)s_cnt[1]);
+    const int t0 = blockIdx.x * 16;
+    const int nvec = D >> 3;
+    for (int i = threadIdx.x; i < 16 * nvec; i += 256) {
+        const int t = t0 + i / nvec, c = i % nvec;
+        if (t >= T) break;
+        const int v = row[t];
+        float o[8];
+        if (v == 1 || v == 32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        } else {
+            const h8 e = *reinterpret_cast<const h8 *>(emb + (int64_t)v * D + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (float)e[j] * scale;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(x + ((int64_t)b * T + t) * D + c * 8);
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+hipError_t launch_esm_embed(const int32_t *tok, const half_t *emb, int B, int T, int D, float *x, hipStream_t s) {
+    hipLaunchKernelGGL(esm_embed_kernel, dim3(cdiv(T, 16), B), dim3(256), 0, s, tok, emb, T, D, x);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ rotary helpers
+// cs table: fp32 [pos][hd/2][2] = (cos, sin) of pos * theta^(-2i/hd).
+// Half-rotation (rotate_half): out[d] = x[d] cos - x[d+half] sin ; out[d+half] = x[d+half] cos + x[d] sin.
+__device__ __forceinline__ void rope8(half_t *base, int half, const float *cs, float scale) {
+    h8 lo = *reinterpret_cast<h8 *>(base);
+    h8 hi = *reinterpret_cast<h8 *>(base + half);
+    h8 olo, ohi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float c = cs[2 * j], sn = cs[2 * j + 1];
+        const float a = (float)lo[j] * scale, b = (float)hi[j] * scale;
+        olo[j] = (half_t)(a * c - b * sn);
+        ohi[j] = (half_t)(b * c + a * sn);
+    }
+    *reinterpret_cast<h8 *>(base) = olo;
+    *reinterpret_cast<h8 *>(base + half) = ohi;
+}
+
+// ESM-2 (E2): q <- rotary(q * hd^-0.5), k <- rotary(k), positions 0..T-1, in place on the fused
+// [B*T, 3D] projection output (query scaled BEFORE the rotation, modeling_esm.py:374).
+__global__ __launch_bounds__(256) void esm_rope_kernel(half_t *__restrict__ qkv, const float *__restrict__ cs, int T,
+                                                       int heads, int hd, float qscale, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int half = hd >> 1, vph = half >> 3;            // 8-wide vectors per half head
+    const int v = (int)(i % vph);
+    int64_t r = i / vph;
+    const int h = (int)(r % heads); r /= heads;
+    const int which = (int)(r & 1);                        // 0 = q, 1 = k
+    const int64_t row = r >> 1;
+    const int t = (int)(row % T);
+    const int D = heads * hd;
+    half_t *base = qkv + row * (3 * (int64_t)D) + which * D + h * hd + v * 8;
+    rope8(base, half, cs + ((int64_t)t * half + v * 8) * 2, which == 0 ? qscale : 1.0f);
+}
+
+hipError_t launch_esm_rope(half_t *qkv, const float *cs, int B, int T, int heads, int hd, float qscale, hipStream_t s) {
+    if (hd & 15) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * T * 2 * heads * (hd >> 4);
+    hipLaunchKernelGGL(esm_rope_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, qkv, cs, T, heads, hd, qscale, total);
+    return hipGetLastError();
+}
+
+// Llama prefill (D1, D4): rotary on q and k at position t - kstart[b] (first real token = 0), in place
+// on the fused [B*T, (nh+2nkv)*hd] buffer, then K and V appended to the cache [b][kvh][slot t][hd].
+__global__ __launch_bounds__(256) void dec_rope_cache_kernel(half_t *__restrict__ qkv, const float *__restrict__ cs,
+                                                             const int32_t *__restrict__ kstart, int T, int nh, int nkv,
+                                                             int hd, half_t *__restrict__ kc, half_t *__restrict__ vc,
+                                                             int64_t cache_sb, int64_t cache_sh, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int half = hd >> 1, vph = half >> 3;
+    const int v = (int)(i % vph);
+    int64_t r = i / vph;
+    const int hh = (int)(r % (nh + nkv)); r /= (nh + nkv);   // q heads then k heads
+    const int64_t row = r;
+    const int b = (int)(row / T), t = (int)(row % T);
+    int pos = t - kstart[b];
+    pos = pos < 0 ? 0 : pos;
+    const int64_t ld = (int64_t)(nh + 2 * nkv) * hd;
+    half_t *base = qkv + row * ld + (int64_t)hh * hd + v * 8;
+    rope8(base, half, cs + ((int64_t)pos * half + v * 8) * 2, 1.0f);
+    if (hh >= nh) {
+        const int kh = hh - nh;
+        half_t *kd = kc + b * cache_sb + kh * cache_sh + (int64_t)t * hd + v * 8;
+        half_t *vd = vc + b * cache_sb + kh * cache_sh + (int64_t)t * hd + v * 8;
+        const half_t *vs = base + (int64_t)nkv * hd;
+        *reinterpret_cast<h8 *>(kd) = *reinterpret_cast<h8 *>(base);
+        *reinterpret_cast<h8 *>(kd + half) = *reinterpret_cast<h8 *>(base + half);
+        *reinterpret_cast<h8 *>(vd) = *reinterpret_cast<const h8 *>(vs);
+        *reinterpret_cast<h8 *>(vd + half) = *reinterpret_cast<const h8 *>(vs + half);
+    }
+}
+
+hipError_t launch_dec_rope_cache(half_t *qkv, const float *cs, const int32_t *kstart, int B, int T, int nh, int nkv,
+                                 int hd, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh, hipStream_t s) {
+    if (hd & 15) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * T * (nh + nkv) * (hd >> 4);
+    hipLaunchKernelGGL(dec_rope_cache_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, qkv, cs, kstart, T, nh, nkv, hd,
+                       kc, vc, cache_sb, cache_sh, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ small copies
+__global__ __launch_bounds__(256) void h2f_kernel(const half_t *__restrict__ in, float *__restrict__ out, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const h8 v = reinterpret_cast<const h8 *>(in)[i];
+    float4 *o = reinterpret_cast<float4 *>(out) + 2 * i;
+    o[0] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    o[1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+}
+hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s) {
+    if (n & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(h2f_kernel, dim3(cdiv(n >> 3, 256)), dim3(256), 0, s, in, out, n >> 3);
+    return hipGetLastError();
+}
+
+// x[b,:] = fp32(emb[tok[b]]) : embedding of the token just generated (input of the next decode step)
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__restrict__ tok, const half_t *__restrict__ emb,
+                                                           int H, int V, float *__restrict__ x) {
+    const int b = blockIdx.x;
+    int id = tok[b];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    for (int c = threadIdx.x; c < (H >> 3); c += 256) {
+        const h8 e = *reinterpret_cast<const h8 *>(emb + (int64_t)id * H + c * 8);
+        float4 *o = reinterpret_cast<float4 *>(x + (int64_t)b * H + c * 8);
+        o[0] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
+        o[1] = make_float4((float)e[4], (float)e[5], (float)e[6], (float)e[7]);
+    }
+}
+hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, hipStream_t s) {
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x);
+    return hipGetLastError();
+}
+
+// out[b,:] = x[b, T-1, :]   (lm_head is applied to the last position only; row D2)
+__global__ __launch_bounds__(256) void take_last_kernel(const float *__restrict__ x, int T, int H, float *__restrict__ out) {
+    const int b = blockIdx.x;
+    const float4 *src = reinterpret_cast<const float4 *>(x + ((int64_t)b * T + (T - 1)) * H);
+    float4 *dst = reinterpret_cast<float4 *>(out + (int64_t)b * H);
+    for (int c = threadIdx.x; c < (H >> 2); c += 256) dst[c] = src[c];
+}
+hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(take_last_kernel, dim3(B), dim3(256), 0, s, x, T, H, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ synthetic fill
+// Bit-identical twin of opus-pllm_amd/synth.py::hash_normal (splitmix64 -> Irwin-Hall(4x16 bit)).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void fill_synth_kernel(void *__restrict__ dst, int dtype, int64_t rows, int64_t cols,
+                                                         uint64_t seed, float scale, float mean, int has_mean,
+                                                         int64_t rb, int64_t rs, int64_t ro) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t z = splitmix64((uint64_t)i + seed);
+        const int sum = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)(z >> 48);
+        float v = __fmul_rn((float)(sum - 131070), scale);
+        if (has_mean) v = __fadd_rn(v, mean);
+        const half_t hv = (half_t)v;           // round-to-nearest-even
+        const int64_t r = i / cols, c = i % cols;
+        const int64_t dr = (r / rb) * rs + ro + (r % rb);
+        if (dtype == 0) reinterpret_cast<half_t *>(dst)[dr * cols + c] = hv;
+        else reinterpret_cast<float *>(dst)[dr * cols + c] = (float)hv;
+    }
+}
+hipError_t launch_fill_synth(void *dst, int dtype, int64_t rows, int64_t cols, uint64_t seed, float std, float mean,
+                             int64_t rb, int64_t rs, int64_t ro, hipStream_t s) {
+    const float ih_std = 37837.2272372065f;   // sqrt(4 * (65536^2 - 1) / 12), rounded to fp32 as NumPy does
+    const float scale = std / ih_std;          // one fp32 divide on the host, as synth.py
+    const int64_t n = rows * cols;
+    int grid = cdiv(n, 256);
+    grid = grid > 8192 ? 8192 : grid;
+    hipLaunchKernelGGL(fill_synth_kernel, dim3(grid), dim3(256), 0, s, dst, dtype, rows, cols, seed, scale, mean,
+                       mean != 0.0f ? 1 : 0, rb, rs, ro);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ LoRA merge (L1)
+// W[o,i] <- fp16(W[o,i] + scale * sum_r B[o,r] A[r,i])   (fp32 accumulation, one rounding)
+__global__ __launch_bounds__(256) void lora_merge_kernel(half_t *__restrict__ W, const half_t *__restrict__ A,
+                                                         const half_t *__restrict__ Bm, float scale, int64_t out_f,
+                                                         int64_t in_f, int r) {
+    const int64_t vec = in_f >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= out_f * vec) return;
+    const int64_t o = i / vec, c = i % vec;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = 0; k < r; ++k) {
+        const float bv = (float)Bm[o * r + k];
+        const h8 a = *reinterpret_cast<const h8 *>(A + (int64_t)k * in_f + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bv * (float)a[j];
+    }
+    h8 *wp = reinterpret_cast<h8 *>(W + o * in_f + c * 8);
+    h8 w = *wp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = (half_t)((float)w[j] + scale * acc[j]);
+    *wp = w;
+}
+hipError_t launch_lora_merge(half_t *W, const half_t *A, const half_t *B, float scale, int64_t out_f, int64_t in_f,
+                             int r, hipStream_t s) {
+    if (in_f & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lora_merge_kernel, dim3(cdiv(out_f * (in_f >> 3), 256)), dim3(256), 0, s, W, A, B, scale, out_f,
+                       in_f, r);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ splice (S1-S3)
+// plan[4b+0] = spliced length of row b (after optional truncation), [4b+1] = first protein block
+// index, [4b+2] = #placeholders, [4b+3] = #valid ids.  plan[4B] = max length, plan[4B+1] = protein
+// blocks consumed (a row without placeholder consumes one: opus_arch.py:196-203), plan[4B+2] = 1 if
+// an id is outside [0,V) and != -200.
+__global__ void splice_plan_kernel(const int64_t *__restrict__ ids, const uint8_t *__restrict__ mask, int B, int Tt,
+                                   int n_tok, int max_len, int V, int32_t *__restrict__ plan) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int seq = 0, tmax = 0, bad = 0;
+    for (int b = 0; b < B; ++b) {
+        int nv = 0, nph = 0;
+        for (int t = 0; t < Tt; ++t) {
+            if (mask && !mask[(int64_t)b * Tt + t]) continue;
+            const int64_t id = ids[(int64_t)b * Tt + t];
+            ++nv;
+            if (id == -200) ++nph;
+            else if (id < 0 || id >= V) bad = 1;
+        }
+        int len = nv - nph + nph * n_tok;
+        if (max_len > 0 && len > max_len) len = max_len;
+        plan[4 * b + 0] = len;
+        plan[4 * b + 1] = seq;
+        plan[4 * b + 2] = nph;
+        plan[4 * b + 3] = nv;
+        seq += nph > 0 ? nph : 1;
+        tmax = len > tmax ? len : tmax;
+    }
+    plan[4 * B] = tmax;
+    plan[4 * B + 1] = seq;
+    plan[4 * B + 2] = bad;
+}
+__global__ __launch_bounds__(256) void splice_fill_kernel(const int64_t *__restrict__ ids, const uint8_t *__restrict__ mask,
+                                                          int Tt, const half_t *__restrict__ prot, int n_tok, int H, int V,
+                                                          const half_t *__restrict__ emb, const int32_t *__restrict__ plan,
+                                                          int Tout, int left_pad, half_t *__restrict__ out,
+                                                          uint8_t *__restrict__ mask_out, int32_t *__restrict__ pos_out) {
+    __shared__ int64_t s_src;      // >= 0: embedding row ; < 0: -(1 + protein_row)
+    const int b = blockIdx.y, to = blockIdx.x;
+    const int len = plan[4 * b];
+    const int j = left_pad ? to - (Tout - len) : to;
+    const bool real = j >= 0 && j < len;
+    if (threadIdx.x == 0) {
+        int64_t src = 0;
+        if (real) {
+            int c = 0, seq = plan[4 * b + 1];
+            for (int t = 0; t < Tt; ++t) {
+                if (mask && !mask[(int64_t)b * Tt + t]) continue;
+                const int64_t id = ids[(int64_t)b * Tt + t];
+                if (id == -200) {
+                    if (j < c + n_tok) { src = -(1 + ((int64_t)seq * n_tok + (j - c))); break; }
+                    c += n_tok;
+                    ++seq;
+                } else {
+                    if (j == c) { src = id < 0 ? 0 : (id >= V ? V - 1 : id); break; }
+                    ++c;
+                }
+            }
+        }
+        s_src = src;
+        mask_out[(int64_t)b * Tout + to] = real ? 1 : 0;
+        pos_out[(int64_t)b * Tout + to] = real ? j : 0;
+    }
+    __syncthreads();
+    const int64_t src = s_src;
+    h8 *dst = reinterpret_cast<h8 *>(out + ((int64_t)b * Tout + to) * H);
+    const h8 *sp = real ? reinterpret_cast<const h8 *>(src >= 0 ? emb + src * H : prot + (-(src + 1)) * H) : nullptr;
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = threadIdx.x; c < (H >> 3); c += 256) dst[c] = real ? sp[c] : zero;
+}
+
+hipError_t launch_splice_plan(const int64_t *ids, const uint8_t *mask, int B, int Tt, int n_tok, int max_len, int V,
+                                int32_t *plan, hipStream_t s) {
+    hipLaunchKernelGGL(splice_plan_kernel, dim3(1), dim3(64), 0, s, ids, mask, B, Tt, n_tok, max_len, V, plan);
+    return hipGetLastError();
+}
+hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, int Tt, const half_t *prot, int n_tok,
+                              int H, int V, const half_t *emb, const int32_t *plan, int Tout, int left_pad,
+                              half_t *out, uint8_t *mask_out, int32_t *pos_out, hipStream_t s) {
+    hipLaunchKernelGGL(splice_fill_kernel, dim3(Tout, B), dim3(256), 0, s, ids, mask, Tt, prot, n_tok, H, V, emb, plan,
+                       Tout, left_pad, out, mask_out, pos_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ greedy step (G1)
+// One workgroup per row: argmax of fp32 logits (lowest index wins ties, as torch.argmax), then the
+// GenerationMixin bookkeeping: finished rows emit pad_id; a row finishes when it emits an EOS id.
+__global__ __launch_bounds__(256) void argmax_step_kernel(const float *__restrict__ logits, int V,
+                                                          const int32_t *__restrict__ eos, int n_eos, int pad_id,
+                                                          int32_t *__restrict__ finished, int32_t *__restrict__ out_ids,
+                                                          int max_new, const int32_t *__restrict__ step,
+                                                          int32_t *__restrict__ next_tok, int32_t *__restrict__ n_unf) {
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    const int b = blockIdx.x;
+    const float *row = logits + (int64_t)b * V;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += 256) {
+        const float v = row[i];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    s_v[threadIdx.x] = bv;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float v = s_v[threadIdx.x + o];
+            const int i = s_i[threadIdx.x + o];
+            if (v > s_v[threadIdx.x] || (v == s_v[threadIdx.x] && i < s_i[threadIdx.x])) {
+                s_v[threadIdx.x] = v;
+                s_i[threadIdx.x] = i;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int st = *step;
+        int fin = finished[b];
+        int tok = fin ? pad_id : (s_i[0] == 0x7fffffff ? 0 : s_i[0]);
+        if (st < max_new) out_ids[(int64_t)b * max_new + st] = tok;
+        if (!fin)
+            for (int e = 0; e < n_eos; ++e) fin |= (tok == eos[e]);
+        finished[b] = fin;
+        next_tok[b] = tok;
+        if (!fin && st < max_new) atomicAdd(&n_unf[st], 1);
+    }
+}
+hipError_t launch_argmax_step(const float *logits, int B, int V, const int32_t *eos, int n_eos, int pad_id,
+                              int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step, int32_t *next_tok,
+                              int32_t *n_unfinished, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(256), 0, s, logits, V, eos, n_eos, pad_id, finished, out_ids,
+                       max_new, step, next_tok, n_unfinished);
+    return hipGetLastError();
+}
+
+__global__ void step_advance_kernel(int32_t *step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+}
+hipError_t launch_step_advance(int32_t *step, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step);
+    return hipGetLastError();
+}
+
+// kstart[b] = index of the first 1 of a left-padded mask row (T if none)
+__global__ void mask_to_kstart_kernel(const uint8_t *__restrict__ mask, int B, int T, int32_t *__restrict__ kstart) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    int k = T;
+    for (int t = 0; t < T; ++t)
+        if (mask[(int64_t)b * T + t]) { k = t; break; }
+    kstart[b] = k;
+}
+hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kstart, hipStream_t s) {
+    hipLaunchKernelGGL(mask_to_kstart_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, mask, B, T, kstart);
+    return hipGetLastError();
+}
+
+}  // namespace opus

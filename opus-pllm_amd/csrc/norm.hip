@@ -1,0 +1,115 @@
+// Row-wise normalisations (HBM-bound, one wave per row, float4 loads, wave64 shuffles).
+//   layernorm : ESM-2 pre-LN / final LN (fp32 in -> fp16 and/or fp32 out)      rows E2, E3
+//   rmsnorm   : Llama RMSNorm, fp32 variance (modeling_llama.py:62-67)           row D1
+//   l2norm    : F.normalize(x, dim=-1) of CSTPBase.protein_forward               row P1
+//   masked_mean: mean over residues 1..len-2 of the final representations        row E4
+#include "common.h"
+
+namespace opus {
+
+constexpr int NV = 20;  // float4 per lane -> rows up to 64*4*20 = 5120 columns
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int MODE>  // 0 layernorm, 1 rmsnorm, 2 l2norm
+__global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ b, float eps, int64_t rows, int D,
+                                                      half_t *__restrict__ out_h, float *__restrict__ out_f) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + row * D);
+    const int nvec = D >> 2;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            v[i] = xr[c];
+            if (MODE == 0) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            else s += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (MODE == 0) {
+        mean = s / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nvec) {
+                const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + bb * bb) + (cc * cc + d * d);
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / D + eps);
+    } else if (MODE == 1) {
+        rstd = rsqrtf(s / D + eps);
+    } else {
+        rstd = 1.0f / fmaxf(sqrtf(s), 1e-12f);   // F.normalize: x / max(||x||, eps)
+    }
+    const float4 *wr = reinterpret_cast<const float4 *>(w);
+    const float4 *br = reinterpret_cast<const float4 *>(b);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            float4 y;
+            y.x = (v[i].x - mean) * rstd; y.y = (v[i].y - mean) * rstd;
+            y.z = (v[i].z - mean) * rstd; y.w = (v[i].w - mean) * rstd;
+            if (MODE != 2) { const float4 ww = wr[c]; y.x *= ww.x; y.y *= ww.y; y.z *= ww.z; y.w *= ww.w; }
+            if (MODE == 0) { const float4 bv = br[c]; y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w; }
+            if (out_h) {
+                h4 o = {(half_t)y.x, (half_t)y.y, (half_t)y.z, (half_t)y.w};
+                reinterpret_cast<h4 *>(out_h + row * D)[c] = o;
+            }
+            if (out_f) reinterpret_cast<float4 *>(out_f + row * D)[c] = y;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float *x, const float *w, const float *b, float eps, int64_t rows, int D,
+                            half_t *out_h, float *out_f, hipStream_t s) {
+    if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rownorm_kernel<0>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, eps, rows, D, out_h, out_f);
+    return hipGetLastError();
+}
+hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t rows, int D, half_t *out, hipStream_t s) {
+    if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rownorm_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, nullptr, eps, rows, D, out,
+                       (float *)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s) {
+    if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rownorm_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, nullptr, nullptr, 0.f, rows, D,
+                       out, (float *)nullptr);
+    return hipGetLastError();
+}
+
+// out[b][d] = mean_{t=1}^{len_b-2} h[b][t][d]; fixed summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float *__restrict__ h, const int32_t *__restrict__ lens,
+                                                          int T, int D, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    const int n = lens[b] - 2;
+    const float *p = h + ((int64_t)b * T + 1) * D + d;
+    float s = 0.f;
+    for (int t = 0; t < n; ++t) s += p[(int64_t)t * D];
+    out[(int64_t)b * D + d] = s / (float)n;   // n == 0 -> NaN, as torch's mean over an empty slice
+}
+
+hipError_t launch_masked_mean(const float *h, const int32_t *lens, int B, int T, int D, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, s, h, lens, T, D, out);
+    return hipGetLastError();
+}
+
+}  // namespace opus

@@ -1,0 +1,327 @@
+"""Host-side mirror of the reference's model interface for the multi_modality_v1 inference path.
+
+Same names, argument meaning and error behaviour as
+  multi_modality_v1/model/language_model/opus_llama.py  (OpusLlamaForCausalLM.generate :95-132)
+  multi_modality_v1/model/opus_arch.py                  (encode_* :103-131,
+                                                          prepare_inputs_labels_for_multimodal :133-294)
+so that eval/run_opus_ddp.py-style callers drop in.  Every tensor op of the path runs in
+libopus_pllm.so; PyTorch only owns device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import types
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _cabi
+from .alphabet import batch_convert
+from .config import OpusConfig
+from .constants import DEFAULT_SEQ_TOKEN_INDEX, IGNORE_INDEX
+from .weights import DeviceWeights
+
+
+class _ProteinEncoderHandle:
+    """What get_protein_encoder() returns: exposes get_protein_seq_embeddings like
+    ProteinSeqEmbeddingExtractor (cstp_v3/modelling.py:37)."""
+
+    def __init__(self, owner: "OpusLlamaForCausalLM"):
+        self._owner = owner
+
+    def get_protein_seq_embeddings(self, data: Sequence[str]) -> torch.Tensor:
+        return self._owner._encode(list(data))
+
+
+class _InnerModel:
+    """What get_model() returns (OpusLlamaModel in the reference): embed_tokens + module handles."""
+
+    def __init__(self, owner: "OpusLlamaForCausalLM"):
+        self._owner = owner
+        self.config = owner.config
+        self.protein_encoder = _ProteinEncoderHandle(owner)
+
+    def get_protein_encoder(self):
+        return self.protein_encoder
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.embedding(ids.to(self._owner.device), self._owner.weights.tensors["dec.emb"])
+
+
+class OpusLlamaForCausalLM:
+    """MI355X-native stand-in for the reference's OpusLlamaForCausalLM (inference only)."""
+
+    def __init__(self, cfg: OpusConfig, weights: DeviceWeights, device: Union[str, torch.device] = "cuda:0",
+                 eos_token_id: Union[int, Sequence[int], None] = None, pad_token_id: Optional[int] = None):
+        self.cfg = cfg.validate()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _cabi.OpusError(-102, "OpusLlamaForCausalLM needs a GPU device: there is no CPU path")
+        self.weights = weights
+        self._lib = _cabi.lib()
+        self._ctx = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        cc = _cabi.CConfig.from_config(cfg)
+        _cabi.check(self._lib.opus_ctx_create(C.byref(cc), idx, C.byref(self._ctx)))
+        weights.bind(self._ctx)
+        self._stream = torch.cuda.Stream(self.device)
+        self.config = types.SimpleNamespace(
+            hidden_size=cfg.dec_dim, vocab_size=cfg.dec_vocab, has_switch_projector=True, has_protein_encoder=True,
+            num_hidden_layers=cfg.dec_layers, device=str(self.device), model_type="opus_llama")
+        eos = [] if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
+        self.generation_config = types.SimpleNamespace(eos_token_id=eos, pad_token_id=pad_token_id)
+        self.model = _InnerModel(self)
+
+    # ------------------------------------------------------------------ lifecycle
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None) and self._ctx.value:
+                self._lib.opus_ctx_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+        except Exception:
+            pass
+
+    def eval(self):
+        return self
+
+    def get_model(self):
+        return self.model
+
+    def get_protein_encoder(self):
+        return self.model.get_protein_encoder()
+
+    # ------------------------------------------------------------------ stream plumbing
+    def _enter(self):
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        return self._stream.cuda_stream
+
+    def _leave(self):
+        torch.cuda.current_stream(self.device).wait_stream(self._stream)
+
+    # ------------------------------------------------------------------ rows E0-E4
+    def _encode(self, seqs: List[str], bucket: int = 64) -> torch.Tensor:
+        """list[str] -> pooled fp32 [B, enc_dim].  Mixed lengths are processed in length buckets
+        (multiples of `bucket` residues) so padding never exceeds one bucket; per-protein results do
+        not depend on the batch they ran in (key padding is masked)."""
+        cfg = self.cfg
+        n = len(seqs)
+        out = torch.empty((n, cfg.enc_dim), dtype=torch.float32, device=self.device)
+        order = sorted(range(n), key=lambda i: len(seqs[i]))
+        groups: List[List[int]] = []
+        for i in order:
+            key = (len(seqs[i]) + bucket - 1) // bucket
+            if groups and groups[-1][0] == key and len(groups[-1][1]) < cfg.max_batch:
+                groups[-1][1].append(i)
+            else:
+                groups.append([key, [i]])
+        s = self._enter()
+        keep = []
+        for _, idxs in groups:
+            toks, lens = batch_convert([seqs[i] for i in idxs])
+            B, T = toks.shape
+            if T > cfg.max_enc_tokens:
+                raise _cabi.OpusError(-2, f"protein of {T - 2} residues exceeds max_enc_tokens={cfg.max_enc_tokens}")
+            with torch.cuda.stream(self._stream):
+                d_tok = torch.from_numpy(toks).to(self.device, non_blocking=True)
+                d_len = torch.from_numpy(lens).to(self.device, non_blocking=True)
+                pooled = torch.empty((B, cfg.enc_dim), dtype=torch.float32, device=self.device)
+                _cabi.check(self._lib.opus_esm2_encode(self._ctx, d_tok.data_ptr(), d_len.data_ptr(), B, T,
+                                                       pooled.data_ptr(), s))
+                out[torch.tensor(idxs, device=self.device)] = pooled
+            keep.append((d_tok, d_len, pooled))
+        self._leave()
+        self._last_enc_shape = (B, T)
+        return out
+
+    def encode_seq2embedding(self, seq) -> torch.Tensor:
+        """opus_arch.py:103-114: str | list[str] -> fp32 [B, enc_dim]; other types: NotImplementedError."""
+        if type(seq) is not list:
+            seq = [seq]
+        if type(seq[0]) is str:
+            return self.get_protein_encoder().get_protein_seq_embeddings(seq)
+        raise NotImplementedError
+
+    def encode_projector_embedding(self, extractor_embedding: torch.Tensor) -> torch.Tensor:
+        """opus_arch.py:115-121 -> CSTPBase.protein_forward (modelling.py:396-400): fp16 [B, proj_dim]."""
+        x = extractor_embedding.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            y = torch.empty((B, self.cfg.switch_in), dtype=torch.float16, device=self.device)
+            _cabi.check(self._lib.opus_protein_projector(self._ctx, x.data_ptr(), B, y.data_ptr(), s))
+        self._leave()
+        return y
+
+    def switch_projector_embedding(self, seq_embedding: torch.Tensor) -> torch.Tensor:
+        """opus_arch.py:122-131: [B, switch_in] -> fp16 [B, n_prot_tokens, hidden]."""
+        y = seq_embedding.to(self.device, torch.float16).contiguous()
+        B = y.shape[0]
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            z = torch.empty((B, self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16, device=self.device)
+            _cabi.check(self._lib.opus_switch_projector(self._ctx, y.data_ptr(), B, z.data_ptr(), s))
+        self._leave()
+        return z
+
+    # ------------------------------------------------------------------ rows S1-S3
+    def _splice(self, input_ids, attention_mask, prot, inference_mode):
+        cfg = self.cfg
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        B, Tt = ids.shape
+        m = None if attention_mask is None else attention_mask.to(self.device).bool().to(torch.uint8).contiguous()
+        prot = prot.to(self.device, torch.float16).contiguous()
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            emb = torch.empty((B, cfg.max_prompt, cfg.dec_dim), dtype=torch.float16, device=self.device)
+            mo = torch.empty((B, cfg.max_prompt), dtype=torch.uint8, device=self.device)
+            po = torch.empty((B, cfg.max_prompt), dtype=torch.int32, device=self.device)
+            T_out = C.c_int32(0)
+            max_len = int(getattr(self.config, "tokenizer_model_max_length", None) or 0)
+            _cabi.check(self._lib.opus_splice_pad(self._ctx, ids.data_ptr(), None if m is None else m.data_ptr(), B, Tt,
+                                                  prot.data_ptr(), prot.shape[0], 1 if inference_mode else 0, max_len,
+                                                  emb.data_ptr(), mo.data_ptr(), po.data_ptr(), C.byref(T_out), s))
+            T = T_out.value
+            # the kernel wrote [B, T] densely at the head of the capacity-sized buffers
+            emb = emb.view(-1)[: B * T * cfg.dec_dim].view(B, T, cfg.dec_dim)
+            mo = mo.view(-1)[: B * T].view(B, T)
+            po = po.view(-1)[: B * T].view(B, T)
+        self._leave()
+        return emb, mo, po
+
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                             seq, seq_embedding=None, inference_mode=False):
+        """opus_arch.py:133-294.  Returns (None, position_ids|None, attention_mask|None, past_key_values,
+        inputs_embeds [B,T,H] fp16, labels|None); inputs unchanged when seq is None or T == 1."""
+        if seq is None or self.get_protein_encoder() is None or input_ids.shape[1] == 1:
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels
+        if seq_embedding is None:
+            seq_embedding = self.encode_seq2embedding(seq)
+        seq_embedding = self.encode_projector_embedding(seq_embedding)
+        if self.config.has_switch_projector:
+            seq_embedding = self.switch_projector_embedding(seq_embedding)
+        if seq_embedding.ndimension() == 2:
+            seq_embedding = seq_embedding.unsqueeze(1)
+        elif seq_embedding.ndimension() != 3:
+            raise NotImplementedError
+        emb, mask_out, pos_out = self._splice(input_ids, attention_mask, seq_embedding, inference_mode)
+        new_labels = None
+        if labels is not None:
+            new_labels = _splice_labels(input_ids, attention_mask, labels, self.cfg.n_prot_tokens, emb.shape[1],
+                                        inference_mode).to(labels.device)
+        out_mask = None if attention_mask is None else mask_out.to(dtype=attention_mask.dtype)
+        out_pos = None if position_ids is None else pos_out.to(dtype=position_ids.dtype)
+        return None, out_pos, out_mask, past_key_values, emb, new_labels
+
+    # ------------------------------------------------------------------ rows G0, G1, D1-D4
+    @torch.no_grad()
+    def generate(self, inputs: Optional[torch.Tensor] = None, seq=None, seq_embedding=None, **kwargs) -> torch.LongTensor:
+        """opus_llama.py:95-132 + GenerationMixin greedy search: returns ONLY the new ids [B, n_new]."""
+        kwargs.pop("position_ids", None)
+        attention_mask = kwargs.pop("attention_mask", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")
+        do_sample = bool(kwargs.pop("do_sample", False))
+        temperature = kwargs.pop("temperature", None)
+        kwargs.pop("top_p", None)
+        num_beams = int(kwargs.pop("num_beams", 1) or 1)
+        max_new = int(kwargs.pop("max_new_tokens", 32))
+        kwargs.pop("use_cache", None)
+        pad_id = kwargs.pop("pad_token_id", self.generation_config.pad_token_id)
+        eos = kwargs.pop("eos_token_id", self.generation_config.eos_token_id)
+        eos = [] if eos is None else ([int(eos)] if isinstance(eos, int) else [int(e) for e in eos])
+        if do_sample and temperature is not None and float(temperature) > 0:
+            raise NotImplementedError("sampling (temperature/top-p) is row N1 of SURVEY 8f: only greedy decode is built")
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not built (greedy only)")
+        if pad_id is None:
+            pad_id = eos[0] if eos else 0
+        if inputs is None:
+            raise ValueError("generate() needs input ids")
+        if seq is not None:
+            _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(
+                inputs, None, attention_mask if attention_mask is not None else torch.ones_like(inputs, dtype=torch.bool),
+                None, None, seq, seq_embedding, inference_mode=True)
+        else:
+            dummy = torch.zeros((inputs.shape[0], self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16,
+                                device=self.device)
+            embeds, mask, _ = self._splice(inputs, attention_mask, dummy, True)
+        return self._greedy(embeds, mask, max_new, eos, int(pad_id))
+
+    def _greedy(self, embeds, mask, max_new, eos, pad_id) -> torch.Tensor:
+        B, T, _ = embeds.shape
+        embeds = embeds.contiguous()
+        mask = mask.to(torch.uint8).contiguous()
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            out = torch.full((B, max_new), pad_id, dtype=torch.int32, device=self.device)
+            n_out = C.c_int32(0)
+            eos_arr = (C.c_int32 * max(1, len(eos)))(*eos)
+            _cabi.check(self._lib.opus_generate_greedy(self._ctx, embeds.data_ptr(), mask.data_ptr(), B, T, max_new,
+                                                       eos_arr, len(eos), pad_id, out.data_ptr(), C.byref(n_out), s))
+        self._leave()
+        return out[:, : n_out.value].long()
+
+    # ------------------------------------------------------------------ parity taps (tests / bench)
+    def prefill_logits(self, embeds: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        B, T, _ = embeds.shape
+        embeds = embeds.to(self.device, torch.float16).contiguous()
+        mask = mask.to(self.device).to(torch.uint8).contiguous()
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            logits = torch.empty((B, self.cfg.dec_vocab), dtype=torch.float32, device=self.device)
+            _cabi.check(self._lib.opus_llama_prefill(self._ctx, embeds.data_ptr(), mask.data_ptr(), B, T,
+                                                     logits.data_ptr(), s))
+        self._leave()
+        return logits
+
+    def decode_logits(self, tok: torch.Tensor) -> torch.Tensor:
+        tok = tok.to(self.device, torch.int32).contiguous()
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            logits = torch.empty((tok.shape[0], self.cfg.dec_vocab), dtype=torch.float32, device=self.device)
+            _cabi.check(self._lib.opus_llama_decode_step(self._ctx, tok.data_ptr(), logits.data_ptr(), s))
+        self._leave()
+        return logits
+
+    def last_hidden(self, B: int, T: int) -> torch.Tensor:
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            h = torch.empty((B, T, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
+            _cabi.check(self._lib.opus_esm2_last_hidden(self._ctx, h.data_ptr(), B, T, s))
+        self._leave()
+        return h
+
+    # ------------------------------------------------------------------ measurement
+    def timing(self, on: bool):
+        _cabi.check(self._lib.opus_timing_enable(self._ctx, 1 if on else 0))
+        _cabi.check(self._lib.opus_timing_reset(self._ctx))
+
+    def timing_get(self, klass: str):
+        ms, n, by = C.c_double(0), C.c_int64(0), C.c_double(0)
+        _cabi.check(self._lib.opus_timing_get(self._ctx, klass.encode(), C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
+
+
+def _splice_labels(input_ids, attention_mask, labels, n_tok, T_out, inference_mode):
+    """Label bookkeeping of opus_arch.py:172-233,255,266 (training-side only; host integer logic)."""
+    ids = input_ids.cpu()
+    lab = labels.cpu()
+    m = torch.ones_like(ids, dtype=torch.bool) if attention_mask is None else attention_mask.cpu().bool()
+    out = torch.full((ids.shape[0], T_out), IGNORE_INDEX, dtype=lab.dtype)
+    for b in range(ids.shape[0]):
+        row: List[int] = []
+        for t in range(ids.shape[1]):
+            if not m[b, t]:
+                continue
+            if int(ids[b, t]) == DEFAULT_SEQ_TOKEN_INDEX:
+                row.extend([IGNORE_INDEX] * n_tok)
+            else:
+                row.append(int(lab[b, t]))
+        row = row[:T_out]
+        if row:
+            if inference_mode:
+                out[b, T_out - len(row):] = torch.tensor(row, dtype=lab.dtype)
+            else:
+                out[b, : len(row)] = torch.tensor(row, dtype=lab.dtype)
+    return out

@@ -1,0 +1,124 @@
+"""CPU-only tests: host-side logic of the product and the C-ABI surface (no compute calls)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import opus_pllm_amd as opa
+from opus_pllm_amd import _cabi, synth
+from opus_pllm_amd.alphabet import batch_convert, encode
+from opus_pllm_amd.weights import fused_spec
+from fake_tokenizer import FakeTokenizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "opus_pllm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(opus_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_cabi.SIGNATURES), declared ^ set(_cabi.SIGNATURES)
+    lib = _cabi.lib()                          # raises if the .so is missing or lacks a symbol
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.opus_abi_version() == 1
+    # pure host entry points that need no GPU
+    cc = _cabi.CConfig.from_config(opa.llama3_8b())
+    assert lib.opus_workspace_bytes(ctypes.byref(cc)) > 1 << 30
+    bad = _cabi.CConfig.from_config(opa.llama3_8b())
+    bad.dec_dim = 4100
+    assert lib.opus_workspace_bytes(ctypes.byref(bad)) == -1
+    assert b"multiple of 64" in lib.opus_last_error()
+
+
+def test_struct_layout_matches_dataclass():
+    cfg = opa.vicuna_13b()
+    cc = _cabi.CConfig.from_config(cfg)
+    assert [n for n, _ in cc._fields_] == list(cfg.to_dict().keys())
+    assert ctypes.sizeof(cc) == 4 * len(cc._fields_)
+    assert cc.dec_vocab == 32000 and abs(cc.dec_rope_theta - 10000.0) < 1e-3
+
+
+def test_tokenizer_seq_token_golden(gold_dir):
+    g = json.load(open(os.path.join(gold_dir, "tokenizer_seq_token.json")))
+    for c in g["cases"]:
+        tok = FakeTokenizer(c["add_bos"])
+        assert opa.tokenizer_seq_token(c["prompt"], tok) == c["ids"], c
+        pt = opa.tokenizer_seq_token(c["prompt"], tok, return_tensors="pt")
+        assert pt.dtype == torch.long and pt.tolist() == c["ids"]
+    with pytest.raises(ValueError) as e:
+        opa.tokenizer_seq_token("a", FakeTokenizer(), return_tensors="np")
+    assert str(e.value) == g["bad_tensor_type_error"]
+
+
+def test_left_pad_sequence():
+    seqs = [torch.tensor([1, 2, 3]), torch.tensor([4]), torch.tensor([], dtype=torch.long)]
+    out = opa.left_pad_sequence(seqs, 9, batch_first=True)
+    assert out.tolist() == [[1, 2, 3], [9, 9, 4], [9, 9, 9]]
+    assert opa.left_pad_sequence(seqs, 9).shape == (3, 3)
+    assert (out != 9).tolist() == [[True] * 3, [False, False, True], [False] * 3]
+
+
+def test_alphabet_golden(gold, gold_dir):
+    g = gold("esm_micro")
+    seqs = json.load(open(os.path.join(gold_dir, "esm_micro.seqs.json")))
+    toks, lens = batch_convert(seqs)
+    assert np.array_equal(toks, g["tokens"]) and np.array_equal(lens, g["lens"])
+    assert encode("L A<mask>G") == [4, 5, 32, 6]
+    with pytest.raises(KeyError):
+        encode("ACDj")
+
+
+def test_synth_is_deterministic_and_fp16_exact():
+    cfg = opa.micro()
+    a, b = synth.canonical_weights(cfg, 5), synth.canonical_weights(cfg, 5)
+    c = synth.canonical_weights(cfg, 6)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+        assert np.array_equal(a[k], a[k].astype(np.float16).astype(np.float32))
+    assert not np.array_equal(a["dec.lm_head.weight"], c["dec.lm_head.weight"])
+    w = a["dec.layers.0.q.weight"]
+    assert abs(w.std() - 2.0 / np.sqrt(cfg.dec_dim)) < 0.02
+    assert synth.synth_protein(16, 0) == synth.synth_protein(16, 0) and len(synth.synth_protein(512, 3)) == 512
+    ids = synth.synth_prompt_ids(128256)
+    assert len(ids) == 89 and ids[41] == -200 and ids[0] == 1 and min(i for i in ids if i >= 0) >= 1
+    ls = synth.synth_lengths(64)
+    assert len(ls) == 64 and min(ls) >= 128 and max(ls) <= 1024
+
+
+def test_fused_spec_covers_every_canonical_tensor_once():
+    for cfg in (opa.micro(), opa.c1_tiny(), opa.llama3_8b(), opa.vicuna_13b()):
+        canon = {n: s for n, s, _, _ in synth.canonical_spec(cfg)}
+        seen = []
+        for f in fused_spec(cfg):
+            rows = 0
+            for p in f.parts:
+                seen.append(p.canon)
+                assert int(np.prod(canon[p.canon])) == p.rows * p.cols
+                rows += p.rows
+            assert rows == f.shape[0]
+        assert sorted(seen) == sorted(canon)
+    assert abs(synth.param_count(opa.llama3_8b()) - 9.93e9) < 5e7
+
+
+def test_config_presets_and_validation():
+    c = opa.llama3_8b()
+    assert (c.enc_layers, c.enc_dim, c.switch_in, c.switch_out, c.dec_kv_dim) == (33, 1280, 5120, 32768, 1024)
+    assert opa.vicuna_13b().switch_out == 40960
+    from opus_pllm_amd.config import switch_depth_from_type
+    assert switch_depth_from_type("mlp2x_gelu") == 2 and switch_depth_from_type("linear") == 1
+    with pytest.raises(ValueError):
+        switch_depth_from_type("conv")
+    with pytest.raises(ValueError):
+        opa.OpusConfig(dec_heads=30).validate()
+
+
+def test_no_cpu_fallback():
+    from opus_pllm_amd.model import OpusLlamaForCausalLM
+    with pytest.raises(_cabi.OpusError):
+        OpusLlamaForCausalLM(opa.micro(), None, "cpu")
