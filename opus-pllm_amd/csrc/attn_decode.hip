@@ -156,14 +156,13 @@ hipError_t launch_attn_decode(const half_t *qkv, const float *cs, const int32_t 
     if (G > MAXG || G * nkv != nh) return hipErrorInvalidValue;
     const int parts = 256 / (hd / 8);
     const size_t lds = ((size_t)MAXG * hd + (size_t)MAXG * ctx_cap + (size_t)parts * G * hd) * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
 #define OPUS_AD(HDV)                                                                                               \
     {                                                                                                              \
-        static bool attr = false;                                                                                  \
-        if (!attr) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_decode_kernel<HDV>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
-            attr = true;                                                                                           \
+        if (lds > 48 * 1024) {                                                                                     \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_decode_kernel<HDV>),         \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+            if (ea != hipSuccess) return ea;                                                                       \
         }                                                                                                          \
         hipLaunchKernelGGL((attn_decode_kernel<HDV>), dim3(nkv, B), dim3(256), lds, s, qkv, cs, kstart, step, T0, \
                            nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out);                              \

@@ -319,8 +319,9 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     const int tm = cdiv(p.M, TBM), tn = cdiv(p.N, TBN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (ea != hipSuccess) return ea;
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 65536, s, p, tm, tn);
