@@ -262,6 +262,25 @@ class OpusLlamaForCausalLM:
         self._leave()
         return out[:, : n_out.value].long()
 
+    def generate_from_tokens(self, d_tokens: torch.Tensor, d_lens: torch.Tensor, input_ids: torch.Tensor,
+                             attention_mask: Optional[torch.Tensor], max_new_tokens: int, eos: Sequence[int] = (),
+                             pad_token_id: int = 0) -> torch.Tensor:
+        """generate() for callers whose inputs are already resident in HBM: ESM-2 token ids int32
+        [B,T] + lens int32 [B] (alphabet.batch_convert), prompt ids int64 [B,T_text] on the device.
+        Same result as generate(input_ids, seqs, ...); used by bench.py for the timed region."""
+        cfg = self.cfg
+        B, T = d_tokens.shape
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            pooled = torch.empty((B, cfg.enc_dim), dtype=torch.float32, device=self.device)
+            _cabi.check(self._lib.opus_esm2_encode(self._ctx, d_tokens.data_ptr(), d_lens.data_ptr(), B, T,
+                                                   pooled.data_ptr(), s))
+            prot = torch.empty((B, cfg.n_prot_tokens, cfg.dec_dim), dtype=torch.float16, device=self.device)
+            _cabi.check(self._lib.opus_projector_forward(self._ctx, pooled.data_ptr(), B, prot.data_ptr(), None, s))
+        self._leave()
+        emb, mask, _ = self._splice(input_ids, attention_mask, prot, True)
+        return self._greedy(emb, mask, int(max_new_tokens), [int(e) for e in eos], int(pad_token_id))
+
     # ------------------------------------------------------------------ parity taps (tests / bench)
     def prefill_logits(self, embeds: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         B, T, _ = embeds.shape
