@@ -68,7 +68,7 @@ int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **out);
 int opus_ctx_destroy(opus_ctx *ctx);
 
 /* Bind one weight tensor (borrowed device pointer).  Names and layouts: DESIGN.md "Weights in HBM"
- * (fused [q;k;v] rows, gate/up interleaved in 16-row groups).  Replaces the state-dict loads of
+ * (fused [q;k;v] rows, gate/up interleaved in 16-row groups, RMSNorm weights folded, panel-tiled).  Replaces the state-dict loads of
  * model/builder.py:60-65,107-111 and opus_arch.py:81-90.  fp16 for matrices, fp32 for vectors. */
 int opus_bind_weight(opus_ctx *ctx, const char *name, const void *d_ptr, int dtype, int ndim,
                      const int64_t *shape);
@@ -82,10 +82,18 @@ int opus_lora_merge(void *d_W, const void *d_A, const void *d_B, float scale, in
                     int32_t r, void *stream);
 
 /* Deterministic synthetic tensor fill (no checkpoints exist offline; opus-pllm_amd/synth.py is the
- * NumPy twin, bit-identical).  Element (row, col) of the LOGICAL [rows, cols] tensor is written at
- * dst row (row / row_block) * row_stride + row_off + row % row_block. */
+ * NumPy twin, bit-identical).  Element (row, col) of the LOGICAL [rows, cols] tensor goes to dst row
+ * (row / row_block) * row_stride + row_off + row % row_block; tiled != 0 writes the panel-tiled GEMM
+ * weight layout (DESIGN.md "Weights in HBM"); fold_std/fold_mean != 0 multiplies column k by element k
+ * of the synthetic vector (fold_seed, fold_std, fold_mean): an RMSNorm weight folded into the
+ * projection that consumes the normalised activations. */
 int opus_fill_synth(void *d_dst, int dtype, int64_t rows, int64_t cols, uint64_t tensor_seed, float std,
-                    float mean, int64_t row_block, int64_t row_stride, int64_t row_off, void *stream);
+                    float mean, int64_t row_block, int64_t row_stride, int64_t row_off, int32_t tiled,
+                    uint64_t fold_seed, float fold_std, float fold_mean, void *stream);
+
+/* Load-time re-layout of one GEMM weight: row-major fp16 W[N,K] (nn.Linear layout) -> the panel-tiled
+ * layout the kernels stream (16-row x 64-k blocks in MFMA B-fragment order).  N % 16 == 0, K % 64 == 0. */
+int opus_tile_weight(const void *d_src, void *d_dst, int64_t N, int64_t K, void *stream);
 
 /* Rows E1-E4: ProteinSeqEmbeddingExtractor.get_protein_seq_embeddings (cstp_v3/modelling.py:37-57):
  * tokens int32 [B,T] (<cls> seq <eos>, pad = 1), lens int32 [B] (incl. <cls>,<eos>) ->
@@ -143,6 +151,9 @@ int opus_generate_greedy(opus_ctx *ctx, const void *d_embeds, const uint8_t *d_m
  * (!causal || j <= i). */
 int opus_debug_gemm(opus_ctx *ctx, const void *d_A, const void *d_W, const float *d_bias, const float *d_residual,
                     void *d_C, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t out_f32, void *stream);
+/* Same with the fused RMSNorm prologue: A is fp32 [M,K], C = epi(rmsnorm(A) W^T) (norm weight folded in W). */
+int opus_debug_gemm_norm(opus_ctx *ctx, const float *d_A, const void *d_W, void *d_C, int32_t M, int32_t N, int32_t K,
+                         int32_t epi, int32_t out_f32, float eps, void *stream);
 int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const void *d_V, void *d_O,
                          const int32_t *d_kstart, const int32_t *d_kend, int32_t B, int32_t T, int32_t heads,
                          int32_t group, int32_t head_dim, int32_t causal, float scale, void *stream);

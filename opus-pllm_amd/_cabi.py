@@ -55,7 +55,8 @@ SIGNATURES = {
     "opus_weights_ready": (C.c_int, [_P]),
     "opus_lora_merge": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, C.c_int64, C.c_int32, _P]),
     "opus_fill_synth": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_float, C.c_float,
-                                  C.c_int64, C.c_int64, C.c_int64, _P]),
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_float, C.c_float, _P]),
+    "opus_tile_weight": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "opus_esm2_encode": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "opus_esm2_last_hidden": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "opus_projector_forward": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "opus_generate_greedy": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                        C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32), _P]),
     "opus_debug_gemm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "opus_debug_gemm_norm": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
     "opus_debug_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_float, _P]),
     "opus_timing_enable": (C.c_int, [_P, C.c_int32]),

@@ -45,8 +45,7 @@ struct EncLayer {
     const float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2;
     const half_t *wqkv, *wo, *w1, *w2;
 };
-struct DecLayer {
-    const float *ln1, *ln2;
+struct DecLayer {   // RMSNorm weights are folded into wqkv / wgu (and dec.lnf into lm_head) at load time
     const half_t *wqkv, *wo, *wgu, *wd;
 };
 
@@ -63,7 +62,7 @@ struct opus_ctx {
     bool resolved = false;
     // resolved weights
     const half_t *enc_emb = nullptr, *dec_emb = nullptr, *lm_head = nullptr, *proj_w = nullptr;
-    const float *enc_lnfw = nullptr, *enc_lnfb = nullptr, *dec_lnf = nullptr, *proj_b = nullptr;
+    const float *enc_lnfw = nullptr, *enc_lnfb = nullptr, *proj_b = nullptr;
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;
     std::vector<const half_t *> sw_w;
@@ -74,10 +73,10 @@ struct opus_ctx {
     float *e_x, *e_hid, *p_pool_dummy;
     half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
     half_t *p_xn, *p_y, *p_z[2];
-    float *d_x, *d_xl, *d_logits;
+    float *d_x, *d_xl, *d_logits, *d_pval;
     half_t *d_xn, *d_qkv, *d_ctx, *d_act, *d_xln, *kc, *vc;
     float *cs_enc, *cs_dec;
-    int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan;
+    int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan, *d_pidx;
     int64_t cache_sl, cache_sb, cache_sh;   // strides (halfs): layer, batch row, kv head
     // decode state
     int cur_B = 0, cur_T = 0;
@@ -148,6 +147,8 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_nunf = k.take<int32_t>((size_t)g.max_new_tokens + 4);
     c->d_eos = k.take<int32_t>(64);
     c->d_plan = k.take<int32_t>(4 * B + 8);
+    c->d_pval = k.take<float>(64 * B);
+    c->d_pidx = k.take<int32_t>(64 * B);
     *total = k.off;
 }
 
@@ -321,14 +322,11 @@ extern "C" int opus_weights_ready(opus_ctx *c) {
     for (int l = 0; l < g.dec_layers; ++l) {
         const std::string p = "dec." + std::to_string(l) + ".";
         DecLayer &L = c->dec[l];
-        GW(p + "ln1", OPUS_F32, (std::vector<int64_t>{H}), L.ln1);
         GW(p + "wqkv", OPUS_F16, (std::vector<int64_t>{QKV, H}), L.wqkv);
         GW(p + "wo", OPUS_F16, (std::vector<int64_t>{H, QD}), L.wo);
-        GW(p + "ln2", OPUS_F32, (std::vector<int64_t>{H}), L.ln2);
         GW(p + "wgu", OPUS_F16, (std::vector<int64_t>{2 * F, H}), L.wgu);
         GW(p + "wd", OPUS_F16, (std::vector<int64_t>{H, F}), L.wd);
     }
-    GW("dec.lnf", OPUS_F32, (std::vector<int64_t>{H}), c->dec_lnf);
     GW("dec.lm_head", OPUS_F16, (std::vector<int64_t>{V, H}), c->lm_head);
     c->resolved = true;
     return OPUS_OK;
@@ -356,13 +354,14 @@ struct Timed {
     }
 };
 
-static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const half_t *W, int M, int N, int K,
-                const float *bias, int epi, const float *residual, void *C, int64_t ldc, int out_f32) {
+static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af, float eps, int64_t lda, const half_t *W,
+                    int M, int N, int K, const float *bias, int epi, const float *residual, void *C, int64_t ldc,
+                    int out_f32) {
     GemmParams p;
-    p.A = A; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias; p.residual = residual;
-    p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
+    p.A = A; p.Af = Af; p.norm_eps = eps; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.residual = residual; p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
-    const double bytes = 2.0 * N * K + 2.0 * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
+    const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
                          (residual ? 4.0 * M * nout : 0.0);
     int klass = M <= 64 ? KC_SKINNY : KC_TILE;
     Timed t(c, s, klass, bytes);
@@ -370,12 +369,25 @@ static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const 
     if (e != hipSuccess) return fail(OPUS_EHIP, "gemm M=%d N=%d K=%d failed: %s", M, N, K, hipGetErrorString(e));
     return OPUS_OK;
 }
+static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const half_t *W, int M, int N, int K,
+                const float *bias, int epi, const float *residual, void *C, int64_t ldc, int out_f32) {
+    return gemm_any(c, s, A, nullptr, 0.f, lda, W, M, N, K, bias, epi, residual, C, ldc, out_f32);
+}
 #define KL(klass, bytes, call)                                                                        \
     do {                                                                                              \
         Timed t_(c, s, klass, bytes);                                                                 \
         hipError_t e_ = (call);                                                                       \
         if (e_ != hipSuccess) return fail(OPUS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+// C = epi(rmsnorm(X) W'^T) with the norm weight pre-folded into W': fused in the skinny kernel (M <= 64),
+// otherwise a weight-less rmsnorm kernel into `scratch` followed by the tile kernel.
+static int gemm_norm(opus_ctx *c, hipStream_t s, const float *X, float eps, half_t *scratch, const half_t *W, int M, int N,
+                     int K, int epi, void *C, int64_t ldc, int out_f32) {
+    if (M <= 64) return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
+    KL(KC_OTHER, 6.0 * M * K, launch_rmsnorm(X, nullptr, eps, M, K, scratch, s));
+    return gemm(c, s, scratch, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
+}
 
 static int need_ready(opus_ctx *c) {
     if (!c) return fail(OPUS_EBADARG, "ctx is null");
@@ -394,10 +406,21 @@ extern "C" int opus_lora_merge(void *W, const void *A, const void *B, float scal
 }
 
 extern "C" int opus_fill_synth(void *dst, int dtype, int64_t rows, int64_t cols, uint64_t seed, float std, float mean,
-                               int64_t row_block, int64_t row_stride, int64_t row_off, void *stream) {
+                               int64_t row_block, int64_t row_stride, int64_t row_off, int32_t tiled, uint64_t fold_seed,
+                               float fold_std, float fold_mean, void *stream) {
     if (!dst || rows < 1 || cols < 1 || (dtype != OPUS_F16 && dtype != OPUS_F32) || row_block < 1 || row_stride < row_block)
         return fail(OPUS_EBADARG, "fill_synth: bad argument");
-    HIPC(launch_fill_synth(dst, dtype, rows, cols, seed, std, mean, row_block, row_stride, row_off, (hipStream_t)stream));
+    if (tiled && (cols % 64 || row_block % 16 || row_stride % 16 || row_off % 16))
+        return fail(OPUS_ESHAPE, "fill_synth: tiled layout needs cols %% 64 == 0 and 16-row aligned blocks");
+    HIPC(launch_fill_synth(dst, dtype, rows, cols, seed, std, mean, row_block, row_stride, row_off, tiled ? 1 : 0,
+                           fold_seed, fold_std, fold_mean, (hipStream_t)stream));
+    return OPUS_OK;
+}
+
+extern "C" int opus_tile_weight(const void *d_src, void *d_dst, int64_t N, int64_t K, void *stream) {
+    if (!d_src || !d_dst || d_src == d_dst) return fail(OPUS_EBADARG, "tile_weight: null or aliased pointers");
+    if (N < 16 || K < 64 || N % 16 || K % 64) return fail(OPUS_ESHAPE, "tile_weight: N %% 16 == 0 and K %% 64 == 0 required");
+    HIPC(launch_tile_weight((const half_t *)d_src, (half_t *)d_dst, N, K, (hipStream_t)stream));
     return OPUS_OK;
 }
 
@@ -514,10 +537,9 @@ extern "C" int opus_splice_pad(opus_ctx *c, const int64_t *d_ids, const uint8_t 
 
 // ------------------------------------------------------------------------------------------------ decoder
 static int lm_head(opus_ctx *c, hipStream_t s, int B) {
-    const opus_config &g = c->cfg;
-    KL(KC_OTHER, 6.0 * B * g.dec_dim, launch_rmsnorm(c->d_xl, c->dec_lnf, g.dec_rms_eps, B, g.dec_dim, c->d_xln, s));
-    return gemm(c, s, c->d_xln, g.dec_dim, c->lm_head, B, g.dec_vocab, g.dec_dim, nullptr, EPI_NONE, nullptr, c->d_logits,
-                g.dec_vocab, 1);
+    const opus_config &g = c->cfg;   // final RMSNorm (folded weight) fused into the lm_head GEMM
+    return gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, c->lm_head, B, g.dec_vocab, g.dec_dim, EPI_NONE, c->d_logits,
+                     g.dec_vocab, 1);
 }
 
 static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8_t *mask, int B, int T) {
@@ -529,8 +551,7 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
     KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
-        KL(KC_OTHER, 6.0 * M * H, launch_rmsnorm(c->d_x, L.ln1, g.dec_rms_eps, M, H, c->d_xn, s));
-        OPC(gemm(c, s, c->d_xn, H, L.wqkv, M, QKV, H, nullptr, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
+        OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wqkv, M, QKV, H, EPI_NONE, c->d_qkv, QKV, 0));
         KL(KC_OTHER, 4.0 * M * QKV,
            launch_dec_rope_cache(c->d_qkv, c->cs_dec, c->d_kstart, B, T, nh, nkv, hd, c->kc + l * c->cache_sl,
                                  c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, s));
@@ -544,8 +565,7 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
         a.scale = 1.0f / sqrtf((float)hd);
         KL(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), launch_attn_prefill(a, s));
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
-        KL(KC_OTHER, 6.0 * M * H, launch_rmsnorm(c->d_x, L.ln2, g.dec_rms_eps, M, H, c->d_xn, s));
-        OPC(gemm(c, s, c->d_xn, H, L.wgu, M, 2 * F, H, nullptr, EPI_SILU_GU16, nullptr, c->d_act, F, 0));
+        OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wgu, M, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
         OPC(gemm(c, s, c->d_act, F, L.wd, M, H, F, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
     }
     KL(KC_OTHER, 8.0 * B * H, launch_take_last(c->d_x, B, T, H, c->d_xl, s));
@@ -568,15 +588,13 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, s));
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
-        KL(KC_OTHER, 6.0 * B * H, launch_rmsnorm(c->d_xl, L.ln1, g.dec_rms_eps, B, H, c->d_xln, s));
-        OPC(gemm(c, s, c->d_xln, H, L.wqkv, B, QKV, H, nullptr, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
+        OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wqkv, B, QKV, H, EPI_NONE, c->d_qkv, QKV, 0));
         KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (T + 1),
            launch_attn_decode(c->d_qkv, c->cs_dec, c->d_kstart, c->d_step, T, B, nh, nkv, hd, c->kc + l * c->cache_sl,
                               c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, ctx_cap, 1.0f / sqrtf((float)hd),
                               c->d_ctx, s));
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, B, H, QD, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
-        KL(KC_OTHER, 6.0 * B * H, launch_rmsnorm(c->d_xl, L.ln2, g.dec_rms_eps, B, H, c->d_xln, s));
-        OPC(gemm(c, s, c->d_xln, H, L.wgu, B, 2 * F, H, nullptr, EPI_SILU_GU16, nullptr, c->d_act, F, 0));
+        OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wgu, B, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
         OPC(gemm(c, s, c->d_act, F, L.wd, B, H, F, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
     }
     OPC(lm_head(c, s, B));
@@ -617,12 +635,19 @@ extern "C" int opus_llama_decode_step(opus_ctx *c, const int32_t *d_tok, float *
     return OPUS_OK;
 }
 
+static int argmax(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id, int32_t *d_out) {
+    const opus_config &g = c->cfg;
+    KL(KC_OTHER, 4.0 * c->cur_B * g.dec_vocab, launch_argmax_partial(c->d_logits, c->cur_B, g.dec_vocab, c->d_pval, c->d_pidx, s));
+    KL(KC_OTHER, 512.0 * c->cur_B,
+       launch_argmax_step(c->d_pval, c->d_pidx, c->cur_B, c->d_eos, n_eos, pad_id, c->d_fin, d_out, max_new, c->d_step,
+                          c->d_next, c->d_nunf, s));
+    return OPUS_OK;
+}
+
 // iteration body of the greedy loop: pick the next token from the current logits, then decode it.
 static int greedy_body(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id, int32_t *d_out) {
     const opus_config &g = c->cfg;
-    KL(KC_OTHER, 4.0 * c->cur_B * g.dec_vocab,
-       launch_argmax_step(c->d_logits, c->cur_B, g.dec_vocab, c->d_eos, n_eos, pad_id, c->d_fin, d_out, max_new, c->d_step,
-                          c->d_next, c->d_nunf, s));
+    OPC(argmax(c, s, max_new, n_eos, pad_id, d_out));
     return decode_step(c, s, c->d_next);
 }
 
@@ -652,9 +677,7 @@ extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uin
     int produced = 0;
     for (int i = 0; i < max_new; ++i) {
         if (i + 1 == max_new) {   // last token: no decode behind it
-            KL(KC_OTHER, 4.0 * B * g.dec_vocab,
-               launch_argmax_step(c->d_logits, B, g.dec_vocab, c->d_eos, n_eos, pad_id, c->d_fin, d_out_ids, max_new,
-                                  c->d_step, c->d_next, c->d_nunf, s));
+            OPC(argmax(c, s, max_new, n_eos, pad_id, d_out_ids));
             produced = i + 1;
             break;
         }
@@ -706,6 +729,17 @@ extern "C" int opus_debug_gemm(opus_ctx *c, const void *A, const void *W, const 
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     return gemm(c, (hipStream_t)stream, (const half_t *)A, K, (const half_t *)W, M, N, K, bias, epi, residual, Cp, nout,
                 out_f32);
+}
+
+extern "C" int opus_debug_gemm_norm(opus_ctx *c, const float *A, const void *W, void *Cp, int32_t M, int32_t N, int32_t K,
+                                    int32_t epi, int32_t out_f32, float eps, void *stream) {
+    if (!c || !A || !W || !Cp) return fail(OPUS_EBADARG, "debug_gemm_norm: null pointer");
+    if (M < 1 || M > 64 || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_norm: M <= 64, K %% 64 == 0");
+    if (epi != 0 && epi != 2) return fail(OPUS_EBADARG, "debug_gemm_norm: epilogue 0 or 2");
+    HIPC(hipSetDevice(c->device));
+    const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
+    return gemm_any(c, (hipStream_t)stream, nullptr, A, eps, K, (const half_t *)W, M, N, K, nullptr, epi, nullptr, Cp, nout,
+                    out_f32);
 }
 
 extern "C" int opus_debug_attention(opus_ctx *c, const void *Q, const void *K, const void *V, void *O,

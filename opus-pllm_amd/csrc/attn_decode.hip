@@ -1,11 +1,12 @@
 // Decode-step attention (row D3/D4): for one new token per batch row,
 //   rotary(q, k) at position slot - kstart[b]  ->  append k, v to the cache at `slot`  ->
-//   softmax(q K^T * scale over keys kstart[b]..slot) V     (GQA: one workgroup per (kv head, row)
-//   serves its `group` query heads so K/V are read once).
-// HBM-bound on the KV cache (2 * ctx * head_dim * 2 B per kv head); K/V go straight to registers
-// (cdna_hip_programming.md Appendix B "Attention decode"): one key per lane for the scores, one
-// 8-wide column slice per lane for PV.  slot = T0 + *step is read from device memory so the same
-// launch can be replayed from a hipGraph.
+//   softmax(q K^T * scale over keys kstart[b]..slot) V.
+// Workgroup = GP query heads of one kv group of one batch row: GP = 1 at small batch (32 workgroups
+// per row instead of 8: the step is latency-bound, so spread it), GP = group at large batch (K/V of a
+// kv head are read once per row).  K/V go straight to registers (cdna_hip_programming.md Appendix B
+// "Attention decode"): two lanes per key for the scores, one 8-wide column slice per lane for PV.
+// The new key/value are used from LDS, so nothing depends on in-launch global visibility.
+// slot = T0 + *step is read from device memory so the same launch can be replayed from a hipGraph.
 #include "common.h"
 
 namespace opus {
@@ -28,7 +29,7 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float *scrat
     return r;
 }
 
-template <int HD>
+template <int HD, int GP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restrict__ qkv, const float *__restrict__ cs,
                                                           const int32_t *__restrict__ kstart_p,
                                                           const int32_t *__restrict__ step_p, int T0, int nh, int nkv,
@@ -36,14 +37,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
                                                           int64_t cache_sb, int64_t cache_sh, int ctx_cap, float scale,
                                                           half_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int HALF = HD / 2, DV = HD / 8, PARTS = 256 / DV;
+    constexpr int HALF = HD / 2, DV = HD / 8, PARTS = 256 / DV, HC = DV / 2;
     const int G = nh / nkv;
-    float *sq = sm;                       // [G][HD]
-    float *sc = sq + MAXG * HD;           // [G][ctx_cap]
-    float *red = sc + MAXG * ctx_cap;     // [PARTS][G][HD]
+    float *sq = sm;                       // [GP][HD]   rotated query heads (fp16-rounded)
+    float *sk = sq + GP * HD;             // [HD]       rotated new key
+    float *sv = sk + HD;                  // [HD]       new value
+    float *sc = sv + HD;                  // [GP][ctx_cap]
+    float *red = sc + GP * ctx_cap;       // [PARTS][GP][HD]
     __shared__ float scratch[4];
 
-    const int kvh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int h0 = blockIdx.x * GP;       // first query head of this workgroup
+    const int kvh = h0 / G;
+    const bool writer = (h0 % G) == 0;    // one workgroup per kv head appends to the cache
     const int slot = T0 + *step_p;
     const int kstart = kstart_p[b];
     const int pos = slot - kstart;
@@ -52,51 +58,72 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
     half_t *kcb = kc + b * cache_sb + kvh * cache_sh;
     half_t *vcb = vc + b * cache_sb + kvh * cache_sh;
 
-    // ---- rotary on the G query heads and the new key; append k, v ----
-    for (int i = tid; i < (G + 1) * HALF; i += 256) {
+    // ---- rotary on the query heads and the new key; stage k, v ----
+    for (int i = tid; i < (GP + 1) * HALF; i += 256) {
         const int j = i / HALF, d = i % HALF;
-        const half_t *src = j < G ? row + (int64_t)(kvh * G + j) * HD : row + (int64_t)(nh + kvh) * HD;
+        const half_t *src = j < GP ? row + (int64_t)(h0 + j) * HD : row + (int64_t)(nh + kvh) * HD;
         const float c = cs[((int64_t)pos * HALF + d) * 2], sn = cs[((int64_t)pos * HALF + d) * 2 + 1];
         const float a = (float)src[d], bb = (float)src[d + HALF];
         const half_t lo = (half_t)(a * c - bb * sn), hi = (half_t)(bb * c + a * sn);
-        if (j < G) {
+        if (j < GP) {
             sq[j * HD + d] = (float)lo;
             sq[j * HD + d + HALF] = (float)hi;
         } else {
-            kcb[(int64_t)slot * HD + d] = lo;
-            kcb[(int64_t)slot * HD + d + HALF] = hi;
-        }
-    }
-    for (int d = tid; d < HD; d += 256) vcb[(int64_t)slot * HD + d] = row[(int64_t)(nh + nkv + kvh) * HD + d];
-    __syncthreads();
-
-    // ---- scores: one key per thread ----
-    const int nkeys = slot - kstart + 1;
-    for (int j = tid; j < nkeys; j += 256) {
-        const h8 *kr = reinterpret_cast<const h8 *>(kcb + (int64_t)(kstart + j) * HD);
-        float acc[MAXG];
-#pragma unroll
-        for (int gi = 0; gi < MAXG; ++gi) acc[gi] = 0.f;
-#pragma unroll
-        for (int c = 0; c < DV; ++c) {
-            const h8 kv = kr[c];
-#pragma unroll
-            for (int gi = 0; gi < MAXG; ++gi) {
-                if (gi < G) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[gi] += (float)kv[e] * sq[gi * HD + c * 8 + e];
-                }
+            sk[d] = (float)lo;
+            sk[d + HALF] = (float)hi;
+            if (writer) {
+                kcb[(int64_t)slot * HD + d] = lo;
+                kcb[(int64_t)slot * HD + d + HALF] = hi;
             }
         }
+    }
+    for (int d = tid; d < HD; d += 256) {
+        const half_t v = row[(int64_t)(nh + nkv + kvh) * HD + d];
+        sv[d] = (float)v;
+        if (writer) vcb[(int64_t)slot * HD + d] = v;
+    }
+    __syncthreads();
+
+    // ---- scores: two lanes per key (each half of the head dim), cached keys then the new one ----
+    const int nkeys = slot - kstart + 1;
+    const int hh = tid & 1;
+    for (int j0 = 0; j0 < nkeys; j0 += 128) {
+        const int j = j0 + (tid >> 1);
+        float acc[GP];
 #pragma unroll
-        for (int gi = 0; gi < MAXG; ++gi)
-            if (gi < G) sc[gi * ctx_cap + j] = acc[gi] * scale;
+        for (int gi = 0; gi < GP; ++gi) acc[gi] = 0.f;
+        if (j < nkeys - 1) {
+            const h8 *kr = reinterpret_cast<const h8 *>(kcb + (int64_t)(kstart + j) * HD) + hh * HC;
+            h8 kv[HC];
+#pragma unroll
+            for (int c = 0; c < HC; ++c) kv[c] = kr[c];
+#pragma unroll
+            for (int c = 0; c < HC; ++c)
+#pragma unroll
+                for (int gi = 0; gi < GP; ++gi)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[gi] += (float)kv[c][e] * sq[gi * HD + (hh * HC + c) * 8 + e];
+        } else if (j == nkeys - 1) {
+#pragma unroll
+            for (int c = 0; c < HC; ++c)
+#pragma unroll
+                for (int gi = 0; gi < GP; ++gi)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc[gi] += sk[(hh * HC + c) * 8 + e] * sq[gi * HD + (hh * HC + c) * 8 + e];
+        }
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi) {
+            const float t = acc[gi] + __shfl_xor(acc[gi], 1, 64);
+            if (hh == 0 && j < nkeys) sc[gi * ctx_cap + j] = t * scale;
+        }
     }
     __syncthreads();
 
     // ---- softmax per head (fp32) ----
-    float linv[MAXG];
-    for (int gi = 0; gi < G; ++gi) {
+    float linv[GP];
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi) {
         float mx = -INFINITY;
         for (int j = tid; j < nkeys; j += 256) mx = fmaxf(mx, sc[gi * ctx_cap + j]);
         mx = block_reduce(mx, true, scratch);
@@ -114,39 +141,77 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
 
     // ---- O = P V : thread = (8-wide column slice, key partition) ----
     const int dv = tid % DV, part = tid / DV;
-    float acc[MAXG][8];
+    float acc[GP][8];
 #pragma unroll
-    for (int gi = 0; gi < MAXG; ++gi)
+    for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[gi][e] = 0.f;
-    for (int j = part; j < nkeys; j += PARTS) {
+    for (int j = part; j < nkeys - 1; j += PARTS) {
         const h8 vv = *reinterpret_cast<const h8 *>(vcb + (int64_t)(kstart + j) * HD + dv * 8);
 #pragma unroll
-        for (int gi = 0; gi < MAXG; ++gi) {
-            if (gi < G) {
-                const float pj = sc[gi * ctx_cap + j];
+        for (int gi = 0; gi < GP; ++gi) {
+            const float pj = sc[gi * ctx_cap + j];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[gi][e] += pj * (float)vv[e];
-            }
+            for (int e = 0; e < 8; ++e) acc[gi][e] += pj * (float)vv[e];
+        }
+    }
+    if (part == (nkeys - 1) % PARTS) {
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi) {
+            const float pj = sc[gi * ctx_cap + nkeys - 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[gi][e] += pj * sv[dv * 8 + e];
         }
     }
 #pragma unroll
-    for (int gi = 0; gi < MAXG; ++gi)
-        if (gi < G) {
+    for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[(part * G + gi) * HD + dv * 8 + e] = acc[gi][e];
-        }
+        for (int e = 0; e < 8; ++e) red[(part * GP + gi) * HD + dv * 8 + e] = acc[gi][e];
     __syncthreads();
-    for (int i = tid; i < G * HD; i += 256) {
+    for (int i = tid; i < GP * HD; i += 256) {
         const int gi = i / HD, d = i % HD;
         float s = 0.f;
-        for (int pp = 0; pp < PARTS; ++pp) s += red[(pp * G + gi) * HD + d];
-        // linv is per-thread identical (block_reduce broadcasts), index by gi at runtime:
+        for (int pp = 0; pp < PARTS; ++pp) s += red[(pp * GP + gi) * HD + d];
         float li = linv[0];
 #pragma unroll
-        for (int q = 1; q < MAXG; ++q) li = (q == gi) ? linv[q] : li;
-        out[(int64_t)b * nh * HD + (int64_t)(kvh * G + gi) * HD + d] = (half_t)(s * li);
+        for (int q = 1; q < GP; ++q) li = (q == gi) ? linv[q] : li;
+        out[(int64_t)b * nh * HD + (int64_t)(h0 + gi) * HD + d] = (half_t)(s * li);
     }
+}
+
+template <int HD, int GP>
+static hipError_t launch_t(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int B,
+                           int nh, int nkv, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh, int ctx_cap,
+                           float scale, half_t *out, hipStream_t s) {
+    const int parts = 256 / (HD / 8);
+    const size_t lds = ((size_t)GP * HD + 2 * HD + (size_t)GP * ctx_cap + (size_t)parts * GP * HD) * sizeof(float);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_decode_kernel<HD, GP>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
+    }
+    hipLaunchKernelGGL((attn_decode_kernel<HD, GP>), dim3(nh / GP, B), dim3(256), lds, s, qkv, cs, kstart, step, T0, nh,
+                       nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out);
+    return hipGetLastError();
+}
+
+template <int HD>
+static hipError_t launch_hd(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int B,
+                            int nh, int nkv, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh, int ctx_cap,
+                            float scale, half_t *out, hipStream_t s) {
+    const int G = nh / nkv;
+    // grouped form only when the per-head form would already fill the chip several times over
+    const bool grouped = G > 1 && (int64_t)B * nkv >= 1024;
+#define OPUS_GO(GPV) return launch_t<HD, GPV>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s)
+    if (!grouped) OPUS_GO(1);
+    switch (G) {
+        case 2: OPUS_GO(2);
+        case 4: OPUS_GO(4);
+        case 8: OPUS_GO(8);
+    }
+    OPUS_GO(1);
+#undef OPUS_GO
 }
 
 hipError_t launch_attn_decode(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step, int T0,
@@ -154,28 +219,13 @@ hipError_t launch_attn_decode(const half_t *qkv, const float *cs, const int32_t 
                               int64_t cache_sh, int ctx_cap, float scale, half_t *out, hipStream_t s) {
     const int G = nh / nkv;
     if (G > MAXG || G * nkv != nh) return hipErrorInvalidValue;
-    const int parts = 256 / (hd / 8);
-    const size_t lds = ((size_t)MAXG * hd + (size_t)MAXG * ctx_cap + (size_t)parts * G * hd) * sizeof(float);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
-#define OPUS_AD(HDV)                                                                                               \
-    {                                                                                                              \
-        if (lds > 48 * 1024) {                                                                                     \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_decode_kernel<HDV>),         \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-            if (ea != hipSuccess) return ea;                                                                       \
-        }                                                                                                          \
-        hipLaunchKernelGGL((attn_decode_kernel<HDV>), dim3(nkv, B), dim3(256), lds, s, qkv, cs, kstart, step, T0, \
-                           nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out);                              \
-    }
     switch (hd) {
-        case 16: OPUS_AD(16) break;
-        case 32: OPUS_AD(32) break;
-        case 64: OPUS_AD(64) break;
-        case 128: OPUS_AD(128) break;
-        default: return hipErrorInvalidValue;
+        case 16: return launch_hd<16>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
+        case 32: return launch_hd<32>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
+        case 64: return launch_hd<64>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
+        case 128: return launch_hd<128>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
     }
-#undef OPUS_AD
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace opus

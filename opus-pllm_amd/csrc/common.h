@@ -17,9 +17,11 @@ enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 
 // C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.
 // EPI_SILU_GU16: W rows come in 32-row groups [16 gate | 16 up]; Nout = N/2, out = silu(g) * u.
 struct GemmParams {
-    const half_t *A;
+    const half_t *A;        // fp16 activations [M,K] (row-major, lda), or
+    const float *Af;        // fp32 residual stream [M,K]: fused RMSNorm (skinny kernel only), else nullptr
+    float norm_eps;
     int64_t lda;
-    const half_t *W;        // row-major [N,K]
+    const half_t *W;        // panel-tiled [N,K] (see gemm.hip)
     int M, N, K;
     const float *bias;      // [N] or nullptr
     const float *residual;  // fp32 [M,Nout] or nullptr (may alias C when C is fp32)
@@ -67,7 +69,10 @@ hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s);
 hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, hipStream_t s);
 hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s);
 hipError_t launch_fill_synth(void *dst, int dtype, int64_t rows, int64_t cols, uint64_t seed, float std,
-                             float mean, int64_t rb, int64_t rs, int64_t ro, hipStream_t s);
+                             float mean, int64_t rb, int64_t rs, int64_t ro, int tiled, uint64_t fold_seed,
+                             float fold_std, float fold_mean, hipStream_t s);
+hipError_t launch_argmax_partial(const float *logits, int B, int V, float *pval, int32_t *pidx, hipStream_t s);
+hipError_t launch_tile_weight(const half_t *src, half_t *dst, int64_t N, int64_t K, hipStream_t s);
 hipError_t launch_lora_merge(half_t *W, const half_t *A, const half_t *B, float scale, int64_t out_f,
                              int64_t in_f, int r, hipStream_t s);
 hipError_t launch_splice_plan(const int64_t *ids, const uint8_t *mask, int B, int Tt, int n_tok, int max_len,
@@ -75,7 +80,7 @@ hipError_t launch_splice_plan(const int64_t *ids, const uint8_t *mask, int B, in
 hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, int Tt, const half_t *prot,
                               int n_tok, int H, int V, const half_t *emb, const int32_t *plan, int Tout,
                               int left_pad, half_t *out, uint8_t *mask_out, int32_t *pos_out, hipStream_t s);
-hipError_t launch_argmax_step(const float *logits, int B, int V, const int32_t *eos, int n_eos, int pad_id,
+hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, int B, const int32_t *eos, int n_eos, int pad_id,
                               int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
                               int32_t *next_tok, int32_t *n_unfinished, hipStream_t s);
 hipError_t launch_step_advance(int32_t *step, hipStream_t s);

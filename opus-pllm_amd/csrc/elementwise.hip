@@ -185,31 +185,63 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
+__device__ __forceinline__ float synth_value(uint64_t seed, uint64_t i, float scale, float mean, int has_mean) {
+    const uint64_t z = splitmix64(i + seed);
+    const int sum = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)(z >> 48);
+    float v = __fmul_rn((float)(sum - 131070), scale);
+    if (has_mean) v = __fadd_rn(v, mean);
+    return (float)(half_t)v;                   // round-to-nearest-even to fp16
+}
+// tiled = 1: destination is the panel-tiled GEMM weight layout of gemm.hip (dst rows % 16 == 0,
+// cols % 64 == 0).  fold: multiply column k by the synthetic vector element (fold_seed, k) - the
+// RMSNorm weight folded into the projection that consumes the normalised activations.
 __global__ __launch_bounds__(256) void fill_synth_kernel(void *__restrict__ dst, int dtype, int64_t rows, int64_t cols,
                                                          uint64_t seed, float scale, float mean, int has_mean,
-                                                         int64_t rb, int64_t rs, int64_t ro) {
+                                                         int64_t rb, int64_t rs, int64_t ro, int tiled, int has_fold,
+                                                         uint64_t fold_seed, float fold_scale, float fold_mean,
+                                                         int fold_has_mean) {
     const int64_t n = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const uint64_t z = splitmix64((uint64_t)i + seed);
-        const int sum = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)(z >> 48);
-        float v = __fmul_rn((float)(sum - 131070), scale);
-        if (has_mean) v = __fadd_rn(v, mean);
-        const half_t hv = (half_t)v;           // round-to-nearest-even
+        float v = synth_value(seed, (uint64_t)i, scale, mean, has_mean);
         const int64_t r = i / cols, c = i % cols;
+        if (has_fold) v = (float)(half_t)__fmul_rn(v, synth_value(fold_seed, (uint64_t)c, fold_scale, fold_mean, fold_has_mean));
         const int64_t dr = (r / rb) * rs + ro + (r % rb);
-        if (dtype == 0) reinterpret_cast<half_t *>(dst)[dr * cols + c] = hv;
-        else reinterpret_cast<float *>(dst)[dr * cols + c] = (float)hv;
+        int64_t off = dr * cols + c;
+        if (tiled) {
+            const int64_t kk = c & 63;
+            off = ((dr >> 4) * (cols >> 6) + (c >> 6)) * 1024 + (kk >> 5) * 512 + ((((kk & 31) >> 3) << 4) + (dr & 15)) * 8 + (kk & 7);
+        }
+        if (dtype == 0) reinterpret_cast<half_t *>(dst)[off] = (half_t)v;
+        else reinterpret_cast<float *>(dst)[off] = v;
     }
 }
 hipError_t launch_fill_synth(void *dst, int dtype, int64_t rows, int64_t cols, uint64_t seed, float std, float mean,
-                             int64_t rb, int64_t rs, int64_t ro, hipStream_t s) {
-    const float ih_std = 37837.2272372065f;   // sqrt(4 * (65536^2 - 1) / 12), rounded to fp32 as NumPy does
+                             int64_t rb, int64_t rs, int64_t ro, int tiled, uint64_t fold_seed, float fold_std,
+                             float fold_mean, hipStream_t s) {
+    const float ih_std = 37837.2272372065f;    // sqrt(4 * (65536^2 - 1) / 12), rounded to fp32 as NumPy does
     const float scale = std / ih_std;          // one fp32 divide on the host, as synth.py
+    const int has_fold = fold_std != 0.0f || fold_mean != 0.0f;
     const int64_t n = rows * cols;
     int grid = cdiv(n, 256);
     grid = grid > 8192 ? 8192 : grid;
     hipLaunchKernelGGL(fill_synth_kernel, dim3(grid), dim3(256), 0, s, dst, dtype, rows, cols, seed, scale, mean,
-                       mean != 0.0f ? 1 : 0, rb, rs, ro);
+                       mean != 0.0f ? 1 : 0, rb, rs, ro, tiled, has_fold, fold_seed, fold_std / ih_std, fold_mean,
+                       fold_mean != 0.0f ? 1 : 0);
+    return hipGetLastError();
+}
+
+// row-major W[N][K] -> panel-tiled layout of gemm.hip (load-time, once per weight)
+__global__ __launch_bounds__(256) void tile_weight_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst,
+                                                          int64_t N, int64_t K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one 16-B piece (8 consecutive k) per thread
+    if (i >= N * (K >> 3)) return;
+    const int64_t n = i / (K >> 3), k8 = i % (K >> 3);
+    const int64_t k = k8 * 8, kk = k & 63;
+    const int64_t off = ((n >> 4) * (K >> 6) + (k >> 6)) * 1024 + (kk >> 5) * 512 + ((((kk & 31) >> 3) << 4) + (n & 15)) * 8;
+    *reinterpret_cast<h8 *>(dst + off) = *reinterpret_cast<const h8 *>(src + n * K + k);
+}
+hipError_t launch_tile_weight(const half_t *src, half_t *dst, int64_t N, int64_t K, hipStream_t s) {
+    hipLaunchKernelGGL(tile_weight_kernel, dim3(cdiv(N * (K >> 3), 256)), dim3(256), 0, s, src, dst, N, K);
     return hipGetLastError();
 }
 
@@ -329,22 +361,35 @@ hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, in
 }
 
 // ------------------------------------------------------------------------------ greedy step (G1)
-// One workgroup per row: argmax of fp32 logits (lowest index wins ties, as torch.argmax), then the
-// GenerationMixin bookkeeping: finished rows emit pad_id; a row finishes when it emits an EOS id.
-__global__ __launch_bounds__(256) void argmax_step_kernel(const float *__restrict__ logits, int V,
-                                                          const int32_t *__restrict__ eos, int n_eos, int pad_id,
-                                                          int32_t *__restrict__ finished, int32_t *__restrict__ out_ids,
-                                                          int max_new, const int32_t *__restrict__ step,
-                                                          int32_t *__restrict__ next_tok, int32_t *__restrict__ n_unf) {
+// Stage 1: APART partial (max, lowest index) per row, float4 loads, many workgroups per row.
+constexpr int APART = 64;
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const float *__restrict__ logits, int V,
+                                                             float *__restrict__ pval, int32_t *__restrict__ pidx) {
     __shared__ float s_v[256];
     __shared__ int s_i[256];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, part = blockIdx.x;
     const float *row = logits + (int64_t)b * V;
+    const int per = ((V + APART - 1) / APART + 3) & ~3;
+    const int lo = part * per, hi = (lo + per < V ? lo + per : V);
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 256) {
-        const float v = row[i];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    if ((((uintptr_t)row) & 15) == 0) {
+        for (int i = lo + threadIdx.x * 4; i + 3 < hi; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + i);
+            if (v.x > bv) { bv = v.x; bi = i; }
+            if (v.y > bv) { bv = v.y; bi = i + 1; }
+            if (v.z > bv) { bv = v.z; bi = i + 2; }
+            if (v.w > bv) { bv = v.w; bi = i + 3; }
+        }
+        for (int i = lo + ((hi - lo) & ~3) + threadIdx.x; i < hi; i += 256) {
+            const float v = row[i];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = row[i];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
     }
     s_v[threadIdx.x] = bv;
     s_i[threadIdx.x] = bi;
@@ -361,9 +406,35 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        pval[b * APART + part] = s_v[0];
+        pidx[b * APART + part] = s_i[0];
+    }
+}
+hipError_t launch_argmax_partial(const float *logits, int B, int V, float *pval, int32_t *pidx, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(APART, B), dim3(256), 0, s, logits, V, pval, pidx);
+    return hipGetLastError();
+}
+
+// Stage 2: one wave per row combines the partials (lowest index wins ties, as torch.argmax), then the
+// GenerationMixin bookkeeping: finished rows emit pad_id; a row finishes when it emits an EOS id.
+__global__ __launch_bounds__(64) void argmax_step_kernel(const float *__restrict__ pval, const int32_t *__restrict__ pidx,
+                                                         const int32_t *__restrict__ eos, int n_eos, int pad_id,
+                                                         int32_t *__restrict__ finished, int32_t *__restrict__ out_ids,
+                                                         int max_new, const int32_t *__restrict__ step,
+                                                         int32_t *__restrict__ next_tok, int32_t *__restrict__ n_unf) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float bv = pval[b * APART + lane];
+    int bi = pidx[b * APART + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v = __shfl_xor(bv, o, 64);
+        const int i = __shfl_xor(bi, o, 64);
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    if (lane == 0) {
         const int st = *step;
         int fin = finished[b];
-        int tok = fin ? pad_id : (s_i[0] == 0x7fffffff ? 0 : s_i[0]);
+        int tok = fin ? pad_id : (bi == 0x7fffffff ? 0 : bi);
         if (st < max_new) out_ids[(int64_t)b * max_new + st] = tok;
         if (!fin)
             for (int e = 0; e < n_eos; ++e) fin |= (tok == eos[e]);
@@ -372,10 +443,10 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float *__restric
         if (!fin && st < max_new) atomicAdd(&n_unf[st], 1);
     }
 }
-hipError_t launch_argmax_step(const float *logits, int B, int V, const int32_t *eos, int n_eos, int pad_id,
+hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, int B, const int32_t *eos, int n_eos, int pad_id,
                               int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step, int32_t *next_tok,
                               int32_t *n_unfinished, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(256), 0, s, logits, V, eos, n_eos, pad_id, finished, out_ids,
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, eos, n_eos, pad_id, finished, out_ids,
                        max_new, step, next_tok, n_unfinished);
     return hipGetLastError();
 }

@@ -1,12 +1,21 @@
 // GEMM kernels for gfx950: C = epi(A W^T + bias) (+ residual), fp16 operands, fp32 accumulation.
 //
-//  * gemm_skinny (M <= 64): weight-streaming kernel for decode / projector / small prefill.  HBM-bound
-//    by construction: every weight byte is loaded exactly once, straight from HBM to registers as
-//    the MFMA B operand (16 B per lane, 128 contiguous bytes per weight row per load pair), K is
-//    split over the waves of a workgroup and combined through LDS.  No LDS staging of weights: they
-//    are not shared between waves (cdna_hip_programming.md "GEMV / M<=16 decode weights" row).
-//  * gemm_tile (M > 64): 128x128x64 LDS-tiled MFMA kernel, register-staged double buffering,
-//    XOR-swizzled LDS (conflict-free ds_read_b128), 4 waves x (64x64) accumulators.
+// Weight layout in HBM ("panel-tiled", built once at load time by weights.py / opus_fill_synth):
+//   W[N][K] is cut into blocks of 16 rows x 64 k; block (p = n/16, c = k/64) is the 2 KB at
+//   ((p * K/64) + c) * 1024 halfs and is stored in MFMA B-fragment order
+//       [s = 0..1][lane = g*16 + li][8 halfs]   with   n = 16p + li,  k = 64c + 32s + 8g + e
+//   so one wave-wide 16-B load fetches 1 KB of contiguous HBM and IS the B operand of one
+//   mfma_f32_16x16x32_f16 (no LDS round trip, no shuffles), and a 16-row panel is one contiguous
+//   K*32-byte stream.  Measured on MI355X (tools/bench_skinny.hip): 6.3-6.8 TB/s vs 4.5-5.3 TB/s for
+//   the same kernel reading row-major weights.
+//
+//  * gemm_skinny (M <= 64): weight-streaming kernel for decode / projectors.  HBM-bound: every weight
+//    byte is loaded exactly once, straight to registers (non-temporal), K is split over the waves of a
+//    workgroup and combined through LDS.  Optional fused RMSNorm prologue: A is the fp32 residual
+//    stream, sum(h^2) is accumulated from the very loads that feed the MFMA and 1/rms is applied in the
+//    epilogue (the norm weight is folded into W at load time), which removes two launches per layer.
+//  * gemm_tile (M > 64): 128x128x64 LDS-tiled MFMA kernel (4 waves x 64x64), register-staged double
+//    buffering; A image XOR-swizzled, B image kept in fragment order (linear ds_read_b128).
 #include "common.h"
 
 namespace opus {
@@ -15,150 +24,262 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
-// skinny: one workgroup = W waves, NT*16 output columns, all M (<= 16*MT) rows; wave w streams the
-// k-chunks [c0,c1) of 64 and the partial 16x16 tiles are summed through LDS.
-// MFMA 16x16x32 f16: A lane (m = l&15, g = l>>4) holds x[m][kslot 8g..8g+7]; B lane holds
-// W[n = l&15][same kslots]; C lane holds C[m = 4g + r][n = l&15].  The k order inside an MFMA is a
-// free permutation as long as A and B agree: each lane takes 16 consecutive k (32 B) per 64-chunk
-// and feeds halves to two MFMAs, so a row's four lane-groups cover one full 128-B line.
-template <int MT, int NT, int EPI>
+// skinny.  Workgroup = PB panels (PB = 2 for the gate/up pair, else 1) x (nwaves / PB) k-parts.
+// MFMA 16x16x32 f16: A lane (m = li, g) holds x[m][32s + 8g + e]; B lane holds the 16 B it loaded;
+// C lane holds C[m = 4g + r][n = li].
+//
+// ALDS (small M: M*K*2 <= 64 KB, i.e. decode): the workgroup first stages the activation rows in LDS
+// as fp16 - with NORM it reads the fp32 residual stream, accumulates sum(h^2) per row on the way and
+// converts - while its first batch of weight loads is already in flight; the main loop then feeds the
+// MFMA A operand from LDS (broadcast reads) and the vector-memory path carries nothing but weights,
+// double-buffered U chunks deep (2 * U KB in flight per wave).
+// !ALDS (16 < M <= 64 or huge K): A fragments come through a buffer descriptor (rows >= M read as
+// zeros without a branch), NORM accumulates sum(h^2) from those same loads.
+template <int MT, int EPI, bool NORM, bool ALDS>
 __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float red[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    constexpr int PB = EPI == EPI_SILU_GU16 ? 2 : 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int n0 = blockIdx.x * (16 * NT);
+    const int wpp = nwaves / PB;                       // waves per panel
+    const int pl = wave / wpp, kpart = wave - pl * wpp;
     const int chunks = p.K >> 6;
-    const int c0 = (int)((int64_t)chunks * wave / nwaves);
-    const int c1 = (int)((int64_t)chunks * (wave + 1) / nwaves);
+    const int npanels = (p.N + 15) >> 4;   // W is stored with its rows padded to a multiple of 16
+    int panel = blockIdx.x * PB + pl;
+    panel = panel < npanels ? panel : npanels - 1;
+    const int c0 = (int)((int64_t)chunks * kpart / wpp);
+    const int c1 = (int)((int64_t)chunks * (kpart + 1) / wpp);
     const int g = lane >> 4, li = lane & 15;
+    // dynamic LDS: [red nwaves*MT*256 f32][rss nwaves*MT*16 f32][wss 16*16 f32][xs M*K f16]
+    float *rss = red + nwaves * MT * 256;
+    float *wss = rss + nwaves * MT * 16;
+    half_t *xs = reinterpret_cast<half_t *>(wss + 256);
 
-    const half_t *wrow[NT];
+    const half_t *wp = p.W + ((int64_t)panel * chunks) * 1024 + lane * 8;
+    f4 acc[MT];
+    float ssq[MT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int n = n0 + 16 * t + li;
-        n = n < p.N ? n : p.N - 1;
-        wrow[t] = p.W + (int64_t)n * p.K + g * 16;
-    }
-    const half_t *arow[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int m = 16 * i + li;
-        m = m < p.M ? m : p.M - 1;
-        arow[i] = p.A + (int64_t)m * p.lda + g * 16;
-    }
-    f4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) { acc[i] = f4{0.f, 0.f, 0.f, 0.f}; ssq[i] = 0.f; }
 
-    // chunks in flight per wave: 2*U*NT weight loads of 16 B per lane (bounded by the 128-VGPR budget
-    // of a 16-wave workgroup)
-    constexpr int U = MT == 1 ? 4 : (MT == 2 ? 2 : 1);
-    int c = c0;
-    for (; c + U <= c1; c += U) {
-        h8 wl[U][NT], wh[U][NT], al[U][MT], ah[U][MT];
+    if constexpr (ALDS) {
+        static_assert(!ALDS || MT == 1, "LDS-staged activations are for M <= 16");
+        constexpr int U = 4;
+        // two NAMED register sets (a runtime-indexed [2][U] array would be placed in scratch)
+        h8 wlA[U], whA[U], wlB[U], whB[U];
+        auto wload = [&](h8 (&wl)[U], h8 (&wh)[U], int c) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const h8 *ptr = reinterpret_cast<const h8 *>(wrow[t] + (int64_t)(c + u) * 64);
-                wl[u][t] = __builtin_nontemporal_load(ptr);
-                wh[u][t] = __builtin_nontemporal_load(ptr + 1);
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const h8 *ptr = reinterpret_cast<const h8 *>(arow[i] + (int64_t)(c + u) * 64);
-                al[u][i] = ptr[0];
-                ah[u][i] = ptr[1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u][i], wl[u][t], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u][i], wh[u][t], acc[i][t], 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                if (c + u < c1) {
+                    const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)(c + u) * 1024);
+                    wl[u] = __builtin_nontemporal_load(ptr);
+                    wh[u] = __builtin_nontemporal_load(ptr + 64);
+                } else {
+                    wl[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                    wh[u] = wl[u];
                 }
-    }
-    for (; c < c1; ++c) {
+            }
+        };
+        wload(wlA, whA, c0);                            // weights first: HBM latency covers the staging
+        // ---- stage A rows (and sum of squares) ----
+        const int nthr = blockDim.x;
+        for (int m = 0; m < p.M; ++m) {
+            if (NORM) {
+                const float4 *src = reinterpret_cast<const float4 *>(p.Af + (int64_t)m * p.lda);
+                float s = 0.f;
+                for (int i = tid; i < (p.K >> 2); i += nthr) {
+                    const float4 v = src[i];
+                    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    *reinterpret_cast<h4 *>(xs + (int64_t)m * p.K + 4 * i) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+                }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const h8 *wp = reinterpret_cast<const h8 *>(wrow[t] + (int64_t)c * 64);
-            h8 wl = __builtin_nontemporal_load(wp), wh = __builtin_nontemporal_load(wp + 1);
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (lane == 0) wss[m * 16 + wave] = s;
+            } else {
+                const h8 *src = reinterpret_cast<const h8 *>(p.A + (int64_t)m * p.lda);
+                for (int i = tid; i < (p.K >> 3); i += nthr)
+                    *reinterpret_cast<h8 *>(xs + (int64_t)m * p.K + 8 * i) = src[i];
+            }
+        }
+        __syncthreads();
+        const int mr = li < p.M ? li : p.M - 1;          // rows >= M duplicate the last row: never stored
+        const h8 *xr = reinterpret_cast<const h8 *>(xs + (int64_t)mr * p.K + g * 8);
+        auto compute = [&](const h8 (&wl)[U], const h8 (&wh)[U], int c) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cc = c + u < c1 ? c + u : c1 - 1;
+                const h8 al = xr[cc * 8], ah = xr[cc * 8 + 4];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wl[u], acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[u], acc[0], 0, 0, 0);
+            }
+        };
+        for (int c = c0; c < c1; c += 2 * U) {
+            if (c + U < c1) wload(wlB, whB, c + U);
+            compute(wlA, whA, c);
+            if (c + U < c1) {
+                if (c + 2 * U < c1) wload(wlA, whA, c + 2 * U);
+                compute(wlB, whB, c + U);
+            }
+        }
+    } else {
+        // A rows through a buffer descriptor: lanes whose row does not exist get an out-of-range
+        // offset, for which the hardware returns zeros without touching memory and without a branch.
+        constexpr int ESZ = NORM ? 4 : 2;
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+            NORM ? (void *)p.Af : (void *)p.A, 0, (int)((int64_t)((p.M - 1) * p.lda + p.K) * ESZ), 0x00020000);
+        int aoff[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = 16 * i + li;
+            aoff[i] = m < p.M ? (int)((m * p.lda + g * 8) * ESZ) : 0x40000000;
+        }
+        // chunks in flight per wave (bounded by the 128-VGPR budget of a 16-wave workgroup)
+        constexpr int U = NORM ? (MT == 1 ? 4 : 1) : (MT == 1 ? 4 : (MT == 2 ? 2 : 1));
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        struct ARaw { u4 v[NORM ? 4 : 2]; };
+        auto load_a = [&](int i, int c, ARaw &r) {
+            const int o = aoff[i] + c * 64 * ESZ;
+            if (NORM) {
+                r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, o, 0, 0);
+                r.v[1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, o + 16, 0, 0);
+                r.v[2] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, o + 128, 0, 0);
+                r.v[3] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, o + 144, 0, 0);
+            } else {
+                r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, o, 0, 0);
+                r.v[1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, o + 64, 0, 0);
+            }
+        };
+        auto conv_a = [&](int i, const ARaw &r, h8 &lo, h8 &hi) {
+            if (NORM) {
+                const float4 a0 = __builtin_bit_cast(float4, r.v[0]), a1 = __builtin_bit_cast(float4, r.v[1]);
+                const float4 b0 = __builtin_bit_cast(float4, r.v[2]), b1 = __builtin_bit_cast(float4, r.v[3]);
+                ssq[i] += (a0.x * a0.x + a0.y * a0.y) + (a0.z * a0.z + a0.w * a0.w) + (a1.x * a1.x + a1.y * a1.y) +
+                          (a1.z * a1.z + a1.w * a1.w) + (b0.x * b0.x + b0.y * b0.y) + (b0.z * b0.z + b0.w * b0.w) +
+                          (b1.x * b1.x + b1.y * b1.y) + (b1.z * b1.z + b1.w * b1.w);
+                lo = h8{(half_t)a0.x, (half_t)a0.y, (half_t)a0.z, (half_t)a0.w, (half_t)a1.x, (half_t)a1.y, (half_t)a1.z, (half_t)a1.w};
+                hi = h8{(half_t)b0.x, (half_t)b0.y, (half_t)b0.z, (half_t)b0.w, (half_t)b1.x, (half_t)b1.y, (half_t)b1.z, (half_t)b1.w};
+            } else {
+                lo = __builtin_bit_cast(h8, r.v[0]);
+                hi = __builtin_bit_cast(h8, r.v[1]);
+            }
+        };
+        int c = c0;
+        for (; c + U <= c1; c += U) {
+            h8 wl[U], wh[U];
+            ARaw ar[U][MT];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)(c + u) * 1024);
+                wl[u] = __builtin_nontemporal_load(ptr);
+                wh[u] = __builtin_nontemporal_load(ptr + 64);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) load_a(i, c + u, ar[u][i]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    h8 al, ah;
+                    conv_a(i, ar[u][i], al, ah);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wl[u], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[u], acc[i], 0, 0, 0);
+                }
+        }
+        for (; c < c1; ++c) {
+            const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)c * 1024);
+            const h8 wl = __builtin_nontemporal_load(ptr), wh = __builtin_nontemporal_load(ptr + 64);
+            ARaw ar[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) load_a(i, c, ar[i]);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const h8 *ap = reinterpret_cast<const h8 *>(arow[i] + (int64_t)c * 64);
-                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap[0], wl, acc[i][t], 0, 0, 0);
-                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap[1], wh, acc[i][t], 0, 0, 0);
+                h8 al, ah;
+                conv_a(i, ar[i], al, ah);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wl, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[i], 0, 0, 0);
+            }
+        }
+        if (NORM) {   // row m's squares sit in the 4 lanes (li = m, g = 0..3)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ssq[i] += __shfl_xor(ssq[i], 16, 64);
+                ssq[i] += __shfl_xor(ssq[i], 32, 64);
             }
         }
     }
 
-    // cross-wave K reduction through LDS: red[wave][i][t][r][lane]
-    if (nwaves > 1) {
+    // cross-wave reduction through LDS: red[wave][i][r][lane] (+ rss[wave][i][16] for !ALDS NORM)
+    if (nwaves > 1 || (NORM && !ALDS)) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[(((wave * MT + i) * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+            for (int r = 0; r < 4; ++r) red[((wave * MT + i) * 4 + r) * 64 + lane] = acc[i][r];
+            if (NORM && !ALDS && g == 0) rss[(wave * MT + i) * 16 + li] = ssq[i];
+        }
         __syncthreads();
         if (wave != 0) return;
+    }
+    f4 up[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        up[i] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s = acc[i][t][r];
-                    for (int w = 1; w < nwaves; ++w) s += red[(((w * MT + i) * NT + t) * 4 + r) * 64 + lane];
-                    acc[i][t][r] = s;
-                }
+        for (int r = 0; r < 4; ++r) {
+            float s = acc[i][r];
+            for (int w = 1; w < wpp; ++w) s += red[((w * MT + i) * 4 + r) * 64 + lane];
+            acc[i][r] = s;
+            if (PB == 2) {
+                float u = 0.f;
+                for (int w = wpp; w < nwaves; ++w) u += red[((w * MT + i) * 4 + r) * 64 + lane];
+                up[i][r] = u;
+            }
+        }
     }
 
-    // epilogue: lane holds C[m = 16i + 4g + r][n = n0 + 16t + li]
+    // epilogue: lane holds C[m = 16i + 4g + r][n = 16 * panel0 + li]
+    const int n0 = blockIdx.x * PB * 16;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = 16 * i + 4 * g + r;
+            const int ml = 4 * g + r;
+            const int m = 16 * i + ml;
             if (m >= p.M) continue;
-            if (EPI == EPI_SILU_GU16) {
-                static_assert(EPI != EPI_SILU_GU16 || NT == 2, "gate/up pairing needs NT == 2");
-                const int ng = n0 + li;
-                if (ng >= p.N) continue;
-                float gate = acc[i][0][r], up = acc[i][NT - 1][r];
-                if (p.bias) { gate += p.bias[ng]; up += p.bias[ng + 16]; }
-                float v = silu(gate) * up;
-                const int no = (n0 >> 1) + li;
-                if (p.residual) v += p.residual[(int64_t)m * p.ldr + no];
-                if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
-                else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int n = n0 + 16 * t + li;
-                    if (n >= p.N) continue;
-                    float v = acc[i][t][r];
-                    if (p.bias) v += p.bias[n];
-                    if (EPI == EPI_GELU) v = gelu_erf(v);
-                    if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
-                    if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + n] = v;
-                    else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + n] = (half_t)v;
-                }
+            float rstd = 1.0f;
+            if (NORM) {
+                float q = 0.f;
+                if (ALDS) for (int w = 0; w < nwaves; ++w) q += wss[m * 16 + w];
+                else for (int w = 0; w < wpp; ++w) q += rss[(w * MT + i) * 16 + ml];
+                rstd = rsqrtf(q / (float)p.K + p.norm_eps);
             }
+            const int n = n0 + li;
+            if (n >= p.N) continue;
+            float v;
+            int no;
+            if (EPI == EPI_SILU_GU16) {
+                float gate = acc[i][r] * rstd, upv = up[i][r] * rstd;
+                if (p.bias) { gate += p.bias[n]; upv += p.bias[n + 16]; }
+                v = silu(gate) * upv;
+                no = (n0 >> 1) + li;
+            } else {
+                v = acc[i][r] * rstd;
+                if (p.bias) v += p.bias[n];
+                if (EPI == EPI_GELU) v = gelu_erf(v);
+                no = n;
+            }
+            if (p.residual) v += p.residual[(int64_t)m * p.ldr + no];
+            if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
+            else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
         }
 }
 
 // ------------------------------------------------------------------------------------------------
 // tile: 128 x 128 x 64, 256 threads = 2x2 waves of 64x64 (4x4 MFMA 16x16x32 tiles each).
-// LDS image per operand: [128 rows][8 chunks of 16 B], chunk c of row r stored at c ^ ((r>>1)&7)
-// (conflict-free for the 16-lane groups of ds_read_b128, see MI355X_MICROARCH.md LDS table).
+// A image: [128 rows][8 chunks of 16 B], chunk c of row r at c ^ ((r>>1)&7) (conflict-free
+// ds_read_b128 for its 16-lane groups).  B image: the 8 weight panels' 2 KB blocks, copied linearly.
 constexpr int TBM = 128, TBN = 128, TBK = 64;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -166,12 +287,11 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [buf][A|B][128][64] halfs : 2 * 2 * 16 KB
-    h8 *lds = reinterpret_cast<h8 *>(smem);
+    h8 *lds = reinterpret_cast<h8 *>(smem);   // [buf][A 1024 | B 1024] h8
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (round-robin), so give
-    // each XCD a contiguous run of tiles that share the same A row-panel in its private L2.
+    // XCD-aware tile order: workgroup ids are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of tiles (neighbours share the A row-panel in that XCD's private L2).
     int bid = blockIdx.x;
     {
         const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
@@ -179,25 +299,27 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
     }
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * TBM, n0 = tn * TBN;
+    const int KT = p.K / TBK;
+    const int npanels = (p.N + 15) >> 4;   // W is stored with its rows padded to a multiple of 16
 
-    // staging: thread handles rows (tid>>3) + 32*i, chunk tid&7
     const int srow = tid >> 3, schunk = tid & 7;
     const half_t *ag[4], *bg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int ra = m0 + srow + 32 * i;
         ra = ra < p.M ? ra : p.M - 1;
-        int rb = n0 + srow + 32 * i;
-        rb = rb < p.N ? rb : p.N - 1;
         ag[i] = p.A + (int64_t)ra * p.lda + schunk * 8;
-        bg[i] = p.W + (int64_t)rb * p.K + schunk * 8;
+        const int q = tid + 256 * i;                       // 16-B piece of the 8-panel B tile
+        int pn = (n0 >> 4) + (q >> 7);
+        pn = pn < npanels ? pn : npanels - 1;
+        bg[i] = p.W + ((int64_t)pn * KT) * 1024 + (q & 127) * 8;
     }
     h8 sa[4], sb[4];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             sa[i] = *reinterpret_cast<const h8 *>(ag[i] + (int64_t)kt * TBK);
-            sb[i] = *reinterpret_cast<const h8 *>(bg[i] + (int64_t)kt * TBK);
+            sb[i] = *reinterpret_cast<const h8 *>(bg[i] + (int64_t)kt * 1024);
         }
     };
     auto lstore = [&](int buf) {
@@ -206,7 +328,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
         for (int i = 0; i < 4; ++i) {
             const int r = srow + 32 * i;
             A[r * 8 + swz(r, schunk)] = sa[i];
-            B[r * 8 + swz(r, schunk)] = sb[i];
+            B[tid + 256 * i] = sb[i];
         }
     };
 
@@ -216,7 +338,6 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = p.K / TBK;
     const int g = lane >> 4, li = lane & 15;
     gload(0);
     lstore(0);
@@ -234,10 +355,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
                 af[i] = A[r * 8 + swz(r, 4 * s + g)];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = wc * 64 + j * 16 + li;
-                bf[j] = B[r * 8 + swz(r, 4 * s + g)];
-            }
+            for (int j = 0; j < 4; ++j) bf[j] = B[(wc * 4 + j) * 128 + s * 64 + lane];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -248,7 +366,6 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
         __syncthreads();
     }
 
-    // epilogue
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -285,31 +402,42 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI>
+template <int MT, int EPI, bool NORM, bool ALDS>
 static hipError_t launch_skinny_t(const GemmParams &p, hipStream_t s) {
-    const int groups = cdiv(p.N, 16 * NT);
+    constexpr int PB = EPI == EPI_SILU_GU16 ? 2 : 1;
+    const int groups = cdiv(p.N, 16 * PB);
     const int chunks = p.K / 64;
-    // enough waves in flight to cover HBM latency: aim for >= 16 waves per CU (4096 on 256 CUs)
-    int W = cdiv(4096, groups);
-    W = W < 4 ? 4 : (W > 16 ? 16 : W);
-    const int wcap = 64 / (MT * NT);   // keep the LDS reduction buffer <= 64 KB
-    if (W > wcap) W = wcap;
-    if (W > chunks) W = chunks;
-    if (W < 1) W = 1;
-    const size_t lds = W > 1 ? (size_t)W * MT * NT * 4 * 64 * sizeof(float) : 0;
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, EPI>), dim3(groups), dim3(64 * W), lds, s, p);
+    // Waves per workgroup W in {4, 8, 16} (divisors of the 16 waves a CU holds at ~100 VGPRs, so whole
+    // workgroups tile the CU), the smallest that puts >= ~3000 waves on the chip (tools/bench_skinny.hip:
+    // the stream saturates from ~8 waves per CU), never more k-parts than 64-wide chunks.
+    int W = (int64_t)groups * 4 >= 3000 ? 4 : ((int64_t)groups * 8 >= 3000 ? 8 : 16);
+    while (W > PB && (W / PB > chunks || (size_t)W * MT * 272 * sizeof(float) > 48 * 1024)) W >>= 1;
+    int wpp = W / PB;
+    if (wpp < 1) wpp = 1;
+    const int W = wpp * PB;
+    const size_t lds = (size_t)W * MT * (256 + 16) * sizeof(float) + 256 * sizeof(float) +
+                       (ALDS ? (size_t)p.M * p.K * sizeof(half_t) : 0);
+    if (lds > 64 * 1024) {
+        static size_t set = 0;
+        if (lds > set) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_skinny_kernel<MT, EPI, NORM, ALDS>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
+            set = lds;
+        }
+    }
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, NORM, ALDS>), dim3(groups), dim3(64 * W), lds, s, p);
     return hipGetLastError();
 }
 
-template <int EPI>
+template <int EPI, bool NORM>
 static hipError_t launch_skinny_e(const GemmParams &p, hipStream_t s) {
-    const int mt = cdiv(p.M, 16);
-    constexpr int NT = (EPI == EPI_SILU_GU16) ? 2 : 1;
-    switch (mt) {
-        case 1: return launch_skinny_t<1, NT, EPI>(p, s);
-        case 2: return launch_skinny_t<2, NT, EPI>(p, s);
+    if (p.M <= 16 && (int64_t)p.M * p.K * 2 <= 64 * 1024) return launch_skinny_t<1, EPI, NORM, true>(p, s);
+    switch (cdiv(p.M, 16)) {
+        case 1: return launch_skinny_t<1, EPI, NORM, false>(p, s);
+        case 2: return launch_skinny_t<2, EPI, NORM, false>(p, s);
         case 3:
-        case 4: return launch_skinny_t<4, NT, EPI>(p, s);
+        case 4: return launch_skinny_t<4, EPI, NORM, false>(p, s);
     }
     return hipErrorInvalidValue;
 }
@@ -333,11 +461,19 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
     if (p.epi == EPI_SILU_GU16 && (p.N & 31)) return hipErrorInvalidValue;
     const bool skinny = p.M <= 64;
     if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;
+    if (p.Af && !skinny) return hipErrorInvalidValue;   // fused norm exists in the skinny kernel only
     if (skinny) {
+        if (p.Af) {
+            switch (p.epi) {
+                case EPI_NONE: return launch_skinny_e<EPI_NONE, true>(p, s);
+                case EPI_SILU_GU16: return launch_skinny_e<EPI_SILU_GU16, true>(p, s);
+            }
+            return hipErrorInvalidValue;
+        }
         switch (p.epi) {
-            case EPI_NONE: return launch_skinny_e<EPI_NONE>(p, s);
-            case EPI_GELU: return launch_skinny_e<EPI_GELU>(p, s);
-            case EPI_SILU_GU16: return launch_skinny_e<EPI_SILU_GU16>(p, s);
+            case EPI_NONE: return launch_skinny_e<EPI_NONE, false>(p, s);
+            case EPI_GELU: return launch_skinny_e<EPI_GELU, false>(p, s);
+            case EPI_SILU_GU16: return launch_skinny_e<EPI_SILU_GU16, false>(p, s);
         }
     } else {
         switch (p.epi) {

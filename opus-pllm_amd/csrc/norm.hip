@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
             float4 y;
             y.x = (v[i].x - mean) * rstd; y.y = (v[i].y - mean) * rstd;
             y.z = (v[i].z - mean) * rstd; y.w = (v[i].w - mean) * rstd;
-            if (MODE != 2) { const float4 ww = wr[c]; y.x *= ww.x; y.y *= ww.y; y.z *= ww.z; y.w *= ww.w; }
+            if (MODE != 2 && w) { const float4 ww = wr[c]; y.x *= ww.x; y.y *= ww.y; y.z *= ww.z; y.w *= ww.w; }
             if (MODE == 0) { const float4 bv = br[c]; y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w; }
             if (out_h) {
                 h4 o = {(half_t)y.x, (half_t)y.y, (half_t)y.z, (half_t)y.w};

@@ -4,21 +4,27 @@ Replaces the state-dict loading of load_pretrained_model / initialize_protein_mo
 (model/builder.py:60-65,107-111; model/opus_arch.py:81-90).  PyTorch owns the device memory; the
 library borrows the pointers through opus_bind_weight.
 
-Fused tensors (fp16 matrices [out, in] row-major = nn.Linear layout, fp32 vectors):
-  enc.emb [33,De] | enc.{l}.ln1.{w,b} | enc.{l}.wqkv [3De,De] = [q;k;v] rows, enc.{l}.bqkv [3De]
-  enc.{l}.wo,bo | enc.{l}.ln2.{w,b} | enc.{l}.w1,b1 | enc.{l}.w2,b2 | enc.lnf.{w,b}
+Fused tensors (fp16 GEMM weights [out, in] = nn.Linear orientation, fp32 vectors):
+  enc.emb [33,De] (row-major gather table) | enc.{l}.ln1.{w,b} | enc.{l}.wqkv [3De,De] = [q;k;v] rows,
+  enc.{l}.bqkv [3De] | enc.{l}.wo,bo | enc.{l}.ln2.{w,b} | enc.{l}.w1,b1 | enc.{l}.w2,b2 | enc.lnf.{w,b}
   proj.{w,b} | sw.{i}.{w,b}
-  dec.emb [V,H] | dec.{l}.ln1 | dec.{l}.wqkv [(nh+2nkv)hd,H] | dec.{l}.wo | dec.{l}.ln2
+  dec.emb [V,H] (row-major gather table) | dec.{l}.wqkv [(nh+2nkv)hd,H] | dec.{l}.wo
   dec.{l}.wgu [2F,H]: 32-row groups = [16 gate rows | 16 up rows] so that a 16-column MFMA tile of
-  gate and its matching tile of up sit in the same lanes (silu(g)*u is lane-local in the epilogue)
-  dec.{l}.wd [H,F] | dec.lnf | dec.lm_head [V,H]
+  gate and its matching tile of up are produced by one workgroup (silu(g)*u in the epilogue)
+  dec.{l}.wd [H,F] | dec.lm_head [V,H]
+Two load-time transforms make the hot loop a pure stream:
+  * every GEMM weight is stored PANEL-TILED (16-row x 64-k blocks in MFMA B-fragment order, see
+    csrc/gemm.hip): one wave-wide 16-B load = 1 KB of contiguous HBM = one MFMA operand;
+  * the decoder's RMSNorm weights are FOLDED into the projection that consumes the normalised
+    activations (wqkv <- wqkv diag(input_norm), wgu <- wgu diag(post_norm), lm_head <- lm_head diag(norm)),
+    fp32 product rounded once to fp16, so the kernels only need 1/rms(x) (computed in the GEMM prologue).
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
 from dataclasses import dataclass
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -43,28 +49,31 @@ class Fused:
     f16: bool
     shape: Tuple[int, ...]
     parts: Tuple[Part, ...]
+    tiled: bool = False          # GEMM weight stored panel-tiled
+    fold: Optional[str] = None   # canonical RMSNorm weight multiplied into the columns
 
 
-def _cat(name, f16, cols, pieces: List[Tuple[str, int]]) -> Fused:
+def _cat(name, f16, cols, pieces: List[Tuple[str, int]], tiled=False, fold=None) -> Fused:
     parts, off = [], 0
     for canon, rows in pieces:
         parts.append(Part(canon, rows, cols, rows, rows, off))
         off += rows
     shape = (off, cols) if f16 or cols > 1 else (off,)
-    return Fused(name, f16, shape, tuple(parts))
+    return Fused(name, f16, shape, tuple(parts), tiled, fold)
 
 
 def fused_spec(cfg: OpusConfig) -> List[Fused]:
     De, Fe = cfg.enc_dim, cfg.enc_ffn
     H, F, V = cfg.dec_dim, cfg.dec_ffn, cfg.dec_vocab
     out: List[Fused] = []
-    mat = lambda n, c, r, k: out.append(_cat(n, True, k, [(c, r)]))       # noqa: E731
+    mat = lambda n, c, r, k, fold=None: out.append(_cat(n, True, k, [(c, r)], True, fold))   # noqa: E731
+    tab = lambda n, c, r, k: out.append(_cat(n, True, k, [(c, r)]))       # noqa: E731  (row-major gather table)
     vec = lambda n, c, r: out.append(_cat(n, False, 1, [(c, r)]))         # noqa: E731
-    mat("enc.emb", "enc.embed_tokens", cfg.enc_vocab, De)
+    tab("enc.emb", "enc.embed_tokens", cfg.enc_vocab, De)
     for l in range(cfg.enc_layers):
         s, d = f"enc.layers.{l}.", f"enc.{l}."
         vec(d + "ln1.w", s + "ln1.weight", De); vec(d + "ln1.b", s + "ln1.bias", De)
-        out.append(_cat(d + "wqkv", True, De, [(s + "q.weight", De), (s + "k.weight", De), (s + "v.weight", De)]))
+        out.append(_cat(d + "wqkv", True, De, [(s + "q.weight", De), (s + "k.weight", De), (s + "v.weight", De)], True))
         out.append(_cat(d + "bqkv", False, 1, [(s + "q.bias", De), (s + "k.bias", De), (s + "v.bias", De)]))
         mat(d + "wo", s + "o.weight", De, De); vec(d + "bo", s + "o.bias", De)
         vec(d + "ln2.w", s + "ln2.weight", De); vec(d + "ln2.b", s + "ln2.bias", De)
@@ -77,25 +86,39 @@ def fused_spec(cfg: OpusConfig) -> List[Fused]:
     for i in range(cfg.switch_depth):
         mat(f"sw.{i}.w", f"switch.{i}.weight", cfg.switch_out, din); vec(f"sw.{i}.b", f"switch.{i}.bias", cfg.switch_out)
         din = cfg.switch_out
-    mat("dec.emb", "dec.embed_tokens", V, H)
+    tab("dec.emb", "dec.embed_tokens", V, H)
     for l in range(cfg.dec_layers):
         s, d = f"dec.layers.{l}.", f"dec.{l}."
-        vec(d + "ln1", s + "input_norm.weight", H)
         out.append(_cat(d + "wqkv", True, H, [(s + "q.weight", cfg.dec_q_dim), (s + "k.weight", cfg.dec_kv_dim),
-                                             (s + "v.weight", cfg.dec_kv_dim)]))
+                                             (s + "v.weight", cfg.dec_kv_dim)], True, s + "input_norm.weight"))
         mat(d + "wo", s + "o.weight", H, cfg.dec_q_dim)
-        vec(d + "ln2", s + "post_norm.weight", H)
         out.append(Fused(d + "wgu", True, (2 * F, H), (Part(s + "gate.weight", F, H, 16, 32, 0),
-                                                       Part(s + "up.weight", F, H, 16, 32, 16))))
+                                                       Part(s + "up.weight", F, H, 16, 32, 16)),
+                         True, s + "post_norm.weight"))
         mat(d + "wd", s + "down.weight", H, F)
-    vec("dec.lnf", "dec.norm.weight", H)
-    mat("dec.lm_head", "dec.lm_head.weight", V, H)
+    mat("dec.lm_head", "dec.lm_head.weight", V, H, "dec.norm.weight")
     return out
 
 
 def _dst_rows(p: Part, device) -> torch.Tensor:
     r = torch.arange(p.rows, device=device)
     return (r // p.rb) * p.rs + p.ro + (r % p.rb)
+
+
+def tile_weight(t: torch.Tensor) -> torch.Tensor:
+    """Row-major fp16 [N,K] on the GPU -> panel-tiled copy (same nominal shape) via opus_tile_weight."""
+    assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.is_contiguous()
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        _cabi.check(_cabi.lib().opus_tile_weight(t.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1],
+                                                 torch.cuda.current_stream(t.device).cuda_stream))
+    return out
+
+
+def untile_weight(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of tile_weight (host-side index arithmetic; tests and debugging only)."""
+    N, K = t.shape
+    return t.reshape(N // 16, K // 64, 2, 4, 16, 8).permute(0, 4, 1, 2, 3, 5).reshape(N, K).contiguous()
 
 
 class DeviceWeights:
@@ -113,16 +136,39 @@ class DeviceWeights:
         return t
 
     @classmethod
-    def from_canonical(cls, cfg: OpusConfig, canon: Dict[str, "np.ndarray | torch.Tensor"], device) -> "DeviceWeights":
-        """Canonical tensors (reference parameter names, see synth.py) -> fused device tensors."""
+    def from_canonical(cls, cfg: OpusConfig, canon: Dict[str, "np.ndarray | torch.Tensor"], device,
+                       lora: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor, float, int]]] = None) -> "DeviceWeights":
+        """Canonical tensors (reference parameter names, see synth.py) -> fused device tensors.
+
+        `lora` maps a canonical weight name to (A [r,in], B [out,r], alpha, r): merged into that weight
+        first, W += (alpha / r) B A, as peft merge_and_unload does at model/builder.py:107-109 (row L1).
+        """
         self = cls(cfg, torch.device(device))
-        for f in fused_spec(cfg):
-            t = self._alloc(f)
-            t2 = t.view(t.shape[0], -1)
-            for p in f.parts:
-                src = torch.as_tensor(np.asarray(canon[p.canon]) if not torch.is_tensor(canon[p.canon]) else canon[p.canon])
-                src = src.to(self.device).reshape(p.rows, p.cols).to(t.dtype)
-                t2[_dst_rows(p, self.device)] = src
+        lib = _cabi.lib()
+
+        def get(name, dtype):
+            v = canon[name]
+            v = torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
+            return v.to(self.device).to(dtype)
+
+        with torch.cuda.device(self.device):
+            for f in fused_spec(cfg):
+                t = self._alloc(f)
+                t2 = t.view(t.shape[0], -1)
+                for p in f.parts:
+                    src = get(p.canon, t.dtype).reshape(p.rows, p.cols).contiguous()
+                    if lora and p.canon in lora:
+                        A, B, alpha, r = lora[p.canon]
+                        A = A.to(self.device, torch.float16).contiguous()
+                        B = B.to(self.device, torch.float16).contiguous()
+                        _cabi.check(lib.opus_lora_merge(src.data_ptr(), A.data_ptr(), B.data_ptr(), float(alpha) / float(r),
+                                                        p.rows, p.cols, int(r), torch.cuda.current_stream().cuda_stream))
+                    t2[_dst_rows(p, self.device)] = src
+                if f.fold is not None:
+                    t.copy_((t.float() * get(f.fold, torch.float32)[None, :]).half())
+                if f.tiled:
+                    self.tensors[f.name] = tile_weight(t)
+            torch.cuda.synchronize(self.device)
         return self
 
     @classmethod
@@ -134,44 +180,16 @@ class DeviceWeights:
         with torch.cuda.device(self.device):
             for f in fused_spec(cfg):
                 t = self._alloc(f)
+                fseed, fstd, fmean = 0, 0.0, 0.0
+                if f.fold is not None:
+                    _, fstd, fmean = spec[f.fold]
+                    fseed = synth.tensor_seed(f.fold, seed)
                 for p in f.parts:
                     _, std, mean = spec[p.canon]
                     _cabi.check(lib.opus_fill_synth(t.data_ptr(), _cabi.OPUS_F16 if f.f16 else _cabi.OPUS_F32,
                                                     p.rows, p.cols, synth.tensor_seed(p.canon, seed), std, mean,
-                                                    p.rb, p.rs, p.ro, stream))
+                                                    p.rb, p.rs, p.ro, 1 if f.tiled else 0, fseed, fstd, fmean, stream))
         return self
-
-    # -- load-time LoRA merge (row L1) -----------------------------------------------------------
-    def merge_lora(self, layer: int, target: str, A: torch.Tensor, B: torch.Tensor, alpha: float, r: int) -> None:
-        """W += (alpha / r) B A on the fused tensor holding decoder projection `target` of `layer`
-        (q/k/v/o/gate/up/down), as peft merge_and_unload does at model/builder.py:107-109."""
-        cfg = self.cfg
-        lib = _cabi.lib()
-        A = A.to(self.device, torch.float16).contiguous()
-        B = B.to(self.device, torch.float16).contiguous()
-        scale = float(alpha) / float(r)
-        pre = f"dec.{layer}."
-        hd = cfg.dec_head_dim
-        if target in ("q", "k", "v"):
-            W = self.tensors[pre + "wqkv"]
-            off = {"q": 0, "k": cfg.dec_q_dim, "v": cfg.dec_q_dim + cfg.dec_kv_dim}[target]
-            rows = cfg.dec_q_dim if target == "q" else cfg.dec_kv_dim
-            sub = W[off:off + rows]
-            _cabi.check(lib.opus_lora_merge(sub.data_ptr(), A.data_ptr(), B.data_ptr(), scale, rows, W.shape[1], r, 0))
-        elif target in ("o", "down"):
-            W = self.tensors[pre + ("wo" if target == "o" else "wd")]
-            _cabi.check(lib.opus_lora_merge(W.data_ptr(), A.data_ptr(), B.data_ptr(), scale, W.shape[0], W.shape[1], r, 0))
-        elif target in ("gate", "up"):
-            # rows are interleaved in 16-row groups: merge group by group on row slices
-            W = self.tensors[pre + "wgu"]
-            ro = 0 if target == "gate" else 16
-            for g in range(cfg.dec_ffn // 16):
-                sub = W[32 * g + ro: 32 * g + ro + 16]
-                Bg = B[16 * g:16 * g + 16].contiguous()
-                _cabi.check(lib.opus_lora_merge(sub.data_ptr(), A.data_ptr(), Bg.data_ptr(), scale, 16, W.shape[1], r, 0))
-        else:
-            raise ValueError(f"unknown LoRA target module: {target}")
-        torch.cuda.synchronize(self.device)
 
     # -- binding ---------------------------------------------------------------------------------
     def bind(self, ctx) -> None:

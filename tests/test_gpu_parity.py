@@ -98,7 +98,13 @@ def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
         acc = (torch.nn.functional.silu(acc[:, :, 0]) * acc[:, :, 1]).reshape(M, nout)
     if resid:
         acc = acc + R.double()
-    dA, dW, db = A.to(dev), W.to(dev), bias.to(dev)
+    from opus_pllm_amd.weights import tile_weight, untile_weight
+    Npad = (N + 15) // 16 * 16                   # weights are bound panel-tiled: rows padded to 16
+    Wp = torch.zeros(Npad, K, dtype=torch.float16)
+    Wp[:N] = W
+    dW = tile_weight(Wp.to(dev))
+    assert torch.equal(untile_weight(dW).cpu(), Wp)
+    dA, db = A.to(dev), bias.to(dev)
     dR = R.to(dev) if resid else None
     out = torch.empty(M, nout, dtype=torch.float32 if f32out else torch.float16, device=dev)
     if resid and f32out:
@@ -311,40 +317,29 @@ def test_generate_c1_golden(dev, gold):
 
 
 def test_lora_merge_vs_oracle(dev):
+    """Row L1: W += (alpha/r) B A merged at load time into the fused / folded / tiled device tensors."""
     import oracle
     from opus_pllm_amd.weights import DeviceWeights
     cfg = opa.micro()
     canon = synth.canonical_weights(cfg, 0)
-    w = DeviceWeights.from_canonical(cfg, canon, dev)
     g = torch.Generator().manual_seed(1)
     r, alpha = 4, 8.0
-    for target, cname in (("q", "q"), ("v", "v"), ("o", "o"), ("gate", "gate"), ("down", "down")):
-        W0 = torch.from_numpy(canon[f"dec.layers.1.{cname}.weight"])
+    lora, merged = {}, dict(canon)
+    for cname in ("q", "v", "o", "gate", "down"):
+        name = f"dec.layers.1.{cname}.weight"
+        W0 = torch.from_numpy(canon[name])
         A = (torch.randn(r, W0.shape[1], generator=g) * 0.1).half()
         B = (torch.randn(W0.shape[0], r, generator=g) * 0.1).half()
-        w.merge_lora(1, target, A, B, alpha, r)
-        ref = oracle.lora_merge(W0, A.float(), B.float(), alpha, r)
-        ref_w = DeviceWeights.from_canonical(cfg, {**canon, f"dec.layers.1.{cname}.weight": ref.numpy()}, dev)
-        key = {"q": "wqkv", "v": "wqkv", "o": "wo", "gate": "wgu", "down": "wd"}[target]
-        got, exp = w.tensors[f"dec.1.{key}"].float().cpu(), ref_w.tensors[f"dec.1.{key}"].float().cpu()
-        # one fp16 ulp of slack: fp32 accumulation order of the rank-r sum differs
-        assert (got - exp).abs().max() <= 2 ** -10 * exp.abs().max(), target
-        canon[f"dec.layers.1.{cname}.weight"] = got_canon(w, cfg, cname, canon)
-
-
-def got_canon(w, cfg, cname, canon):
-    """read the merged canonical tensor back out of the fused device tensor"""
-    t = w.tensors
-    if cname == "q":
-        return t["dec.1.wqkv"][: cfg.dec_q_dim].float().cpu().numpy()
-    if cname == "v":
-        return t["dec.1.wqkv"][cfg.dec_q_dim + cfg.dec_kv_dim:].float().cpu().numpy()
-    if cname == "o":
-        return t["dec.1.wo"].float().cpu().numpy()
-    if cname == "down":
-        return t["dec.1.wd"].float().cpu().numpy()
-    W = t["dec.1.wgu"].float().cpu().view(cfg.dec_ffn // 16, 2, 16, -1)
-    return W[:, 0].reshape(cfg.dec_ffn, -1).numpy()
+        lora[name] = (A, B, alpha, r)
+        merged[name] = oracle.lora_merge(W0, A.float(), B.float(), alpha, r).numpy()
+    got = DeviceWeights.from_canonical(cfg, canon, dev, lora=lora)
+    exp = DeviceWeights.from_canonical(cfg, merged, dev)
+    for key in ("dec.1.wqkv", "dec.1.wo", "dec.1.wgu", "dec.1.wd"):
+        a_, b_ = got.tensors[key].float().cpu(), exp.tensors[key].float().cpu()
+        # one fp16 ulp of slack: the fp32 accumulation order of the rank-r sum differs
+        assert (a_ - b_).abs().max() <= 2 ** -9 * b_.abs().max(), key
+        assert not torch.equal(a_, DeviceWeights.from_canonical(cfg, canon, dev).tensors[key].float().cpu())
+    assert torch.equal(got.tensors["dec.0.wqkv"], exp.tensors["dec.0.wqkv"])       # untouched layer
 
 
 # ------------------------------------------------------------------------------------------------ mid-size model

@@ -102,6 +102,11 @@ def test_fused_spec_covers_every_canonical_tensor_once():
                 assert int(np.prod(canon[p.canon])) == p.rows * p.cols
                 rows += p.rows
             assert rows == f.shape[0]
+            if f.fold:                       # RMSNorm weight folded into this projection's columns
+                seen.append(f.fold)
+                assert f.tiled and canon[f.fold] == (f.shape[1],)
+            if f.tiled:
+                assert f.shape[0] % 16 == 0 and f.shape[1] % 64 == 0
         assert sorted(seen) == sorted(canon)
     assert abs(synth.param_count(opa.llama3_8b()) - 9.93e9) < 5e7
 
