@@ -414,7 +414,7 @@ static hipError_t launch_skinny_t(const GemmParams &p, hipStream_t s) {
     while (W > PB && (W / PB > chunks || (size_t)W * MT * 272 * sizeof(float) > 48 * 1024)) W >>= 1;
     int wpp = W / PB;
     if (wpp < 1) wpp = 1;
-    const int W = wpp * PB;
+    W = wpp * PB;
     const size_t lds = (size_t)W * MT * (256 + 16) * sizeof(float) + 256 * sizeof(float) +
                        (ALDS ? (size_t)p.M * p.K * sizeof(half_t) : 0);
     if (lds > 64 * 1024) {
