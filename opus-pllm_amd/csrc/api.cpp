@@ -73,7 +73,8 @@ struct opus_ctx {
     float *e_x, *e_hid, *p_pool_dummy;
     half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
     half_t *p_xn, *p_y, *p_z[2];
-    float *d_x, *d_xl, *d_logits, *d_pval;
+    float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws;
+    int64_t gemm_ws_bytes = 0;
     half_t *d_xn, *d_qkv, *d_ctx, *d_act, *d_xln, *kc, *vc;
     float *cs_enc, *cs_dec;
     int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan, *d_pidx;
@@ -148,6 +149,8 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_eos = k.take<int32_t>(64);
     c->d_plan = k.take<int32_t>(4 * B + 8);
     c->d_pval = k.take<float>(64 * B);
+    c->gemm_ws_bytes = 64ll << 20;   // split-K slabs of the tile GEMM
+    c->gemm_ws = k.take<float>((size_t)c->gemm_ws_bytes / sizeof(float));
     c->d_pidx = k.take<int32_t>(64 * B);
     *total = k.off;
 }
@@ -360,6 +363,7 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     GemmParams p;
     p.A = A; p.Af = Af; p.norm_eps = eps; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.residual = residual; p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
+    p.ws = c->gemm_ws; p.ws_bytes = c->gemm_ws_bytes;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
                          (residual ? 4.0 * M * nout : 0.0);

@@ -30,6 +30,8 @@ struct GemmParams {
     int64_t ldc;
     int out_f32;            // 1: C is fp32, 0: fp16
     int epi;
+    float *ws;              // split-K workspace (fp32 partial slabs) or nullptr
+    int64_t ws_bytes;
 };
 
 // Flash-style attention over strided Q/K/V (fp16).  Q(b,h,t,:) = Q + b*q_sb + t*q_st + h*HD etc.;

@@ -285,7 +285,7 @@ constexpr int TBM = 128, TBN = 128, TBK = 64;
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_m, int tiles_n, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h8 *lds = reinterpret_cast<h8 *>(smem);   // [buf][A 1024 | B 1024] h8
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -297,9 +297,16 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
         const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
         bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     }
+    // split-K (few output tiles, long K): slice `ks` of a tile accumulates k-tiles [kt0, kt1) and
+    // stores its raw fp32 tile into slab ks of the workspace; splitk_reduce_kernel sums the slabs in a
+    // fixed order (bitwise reproducible, no atomics) and applies the epilogue.
+    const int ntile = tiles_m * tiles_n;
+    const int ks = bid / ntile;
+    bid -= ks * ntile;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * TBM, n0 = tn * TBN;
     const int KT = p.K / TBK;
+    const int kt0 = (int)((int64_t)KT * ks / ksplit), kt1 = (int)((int64_t)KT * (ks + 1) / ksplit);
     const int npanels = (p.N + 15) >> 4;   // W is stored with its rows padded to a multiple of 16
 
     const int srow = tid >> 3, schunk = tid & 7;
@@ -339,12 +346,12 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, li = lane & 15;
-    gload(0);
-    lstore(0);
+    gload(kt0);
+    lstore(kt0 & 1);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) gload(kt + 1);
+        if (kt + 1 < kt1) gload(kt + 1);
         const h8 *A = lds + buf * 2048, *B = A + 1024;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -362,10 +369,26 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) lstore(buf ^ 1);
+        if (kt + 1 < kt1) lstore(buf ^ 1);
         __syncthreads();
     }
 
+    if (ksplit > 1) {
+        float *slab = p.ws + (int64_t)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 64 + i * 16 + 4 * g + r;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wc * 64 + j * 16 + li;
+                    if (n < p.N) slab[(int64_t)m * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -442,6 +465,35 @@ static hipError_t launch_skinny_e(const GemmParams &p, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// out[m][no] = epi(sum_ks slab[ks][m][n] + bias) (+ residual): one thread per output element.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ksplit) {
+    const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)p.M * nout) return;
+    const int m = (int)(i / nout), no = (int)(i % nout);
+    const int64_t slab = (int64_t)p.M * p.N;
+    float v;
+    if (EPI == EPI_SILU_GU16) {
+        const int n = (no >> 4) * 32 + (no & 15);
+        float gate = 0.f, up = 0.f;
+        for (int k = 0; k < ksplit; ++k) {
+            gate += p.ws[k * slab + (int64_t)m * p.N + n];
+            up += p.ws[k * slab + (int64_t)m * p.N + n + 16];
+        }
+        if (p.bias) { gate += p.bias[n]; up += p.bias[n + 16]; }
+        v = silu(gate) * up;
+    } else {
+        v = 0.f;
+        for (int k = 0; k < ksplit; ++k) v += p.ws[k * slab + (int64_t)m * p.N + no];
+        if (p.bias) v += p.bias[no];
+        if (EPI == EPI_GELU) v = gelu_erf(v);
+    }
+    if (p.residual) v += p.residual[(int64_t)m * p.ldr + no];
+    if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
+    else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
+}
+
 template <int EPI>
 static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     const int tm = cdiv(p.M, TBM), tn = cdiv(p.N, TBN);
@@ -452,7 +504,22 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
         if (ea != hipSuccess) return ea;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 65536, s, p, tm, tn);
+    // Too few output tiles to fill 256 CUs (B = 1 prefill, single-protein encoder): split K so that
+    // ~256-320 workgroups stream the weights, at least 4 k-tiles each, slabs within the workspace.
+    const int ntile = tm * tn, KT = p.K / TBK;
+    int ks = 1;
+    if (p.ws && ntile < 160) {
+        ks = 320 / ntile;
+        ks = ks > 8 ? 8 : ks;
+        if (ks > KT / 4) ks = KT / 4;
+        while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
+        if (ks < 1) ks = 1;
+    }
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(ntile * ks), dim3(256), 65536, s, p, tm, tn, ks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, p, ks);
     return hipGetLastError();
 }
 
