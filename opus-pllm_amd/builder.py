@@ -1,0 +1,230 @@
+"""load_pretrained_model: same signature and return value as the reference's
+multi_modality_v1/model/builder.py:29-131, building the MI355X-native model instead of the HF/peft one.
+
+The four artefacts of an OPUS-PLLM deployment (SURVEY section 5 "Checkpoint / resume") are read into
+the canonical tensor names of synth.py and handed to DeviceWeights (fuse, LoRA-merge, fold, tile):
+  1. HF base dir            <model_base_path>/config.json + *.safetensors          (builder.py:60-65)
+  2. PEFT LoRA adapter      <adapter>/lora_adapter/{adapter_config.json, adapter_model.*}   (:107-109)
+  3. refinement projector   <adapter>/modality_refinement_projector/modality_refinement_projection.bin
+                            keys containing 'switch_projector.'  (opus_arch.py:85-89)       (:111)
+  4. CSTP encoding adapter  <adapter>/modality_encoder/modality_encoding_adapter.ckpt, Lightning ckpt holding
+                            protein_projection.linear.{weight,bias} (protein_projector/builder.py:15-25)
+plus the ESM-2 checkpoint the reference pulls from the fair_esm hub cache (cstp_v3/modelling.py:21),
+looked up in $OPUS_ESM2_CKPT or ~/.cache/torch/hub/checkpoints/esm2_t33_650M_UR50D.pt.
+No network access is attempted: a missing artefact raises FileNotFoundError naming it.
+
+Offline / benchmark use: model_base_path = "synthetic:<preset>" (llama3_8b, vicuna_13b, c1_tiny, micro)
+builds the deterministic synthetic model on the GPU and returns a hash tokenizer.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import warnings
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .config import OpusConfig, PRESETS, esm2_dims, switch_depth_from_type
+from .model import OpusLlamaForCausalLM
+from .weights import DeviceWeights
+
+
+def return_cstp_path(args_path: str, file_name: str) -> str:
+    """model/builder.py:19-23."""
+    return f"{args_path}{file_name}" if args_path[-1] == "/" else f"{args_path}/{file_name}"
+
+
+class SyntheticTokenizer:
+    """Whitespace hash tokenizer for the synthetic presets (no tokenizer files exist offline).
+    pad = unk = eos, as the reference sets for Llama tokenizers (builder.py:69-70)."""
+
+    def __init__(self, vocab_size: int, bos_token_id: int = 1, eos_token_id: int = 2):
+        self.vocab_size = vocab_size
+        self.bos_token_id = bos_token_id
+        self.eos_token_id = self.pad_token_id = self.unk_token_id = eos_token_id
+        self.pad_token = self.unk_token = self.eos_token = "</s>"
+
+    def __call__(self, text: str):
+        import types
+        ids = [self.bos_token_id]
+        for w in text.split():
+            h = 0
+            for ch in w:
+                h = (h * 131 + ord(ch)) % 1000003
+            ids.append(3 + h % (self.vocab_size - 3))
+        return types.SimpleNamespace(input_ids=ids)
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        out = []
+        for row in (ids.tolist() if torch.is_tensor(ids) else ids):
+            toks = [t for t in row if not (skip_special_tokens and t in (self.bos_token_id, self.eos_token_id))]
+            out.append(" ".join(f"<{t}>" for t in toks))
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ artefact readers
+def _load_safetensors_dir(path: str) -> Dict[str, torch.Tensor]:
+    from safetensors.torch import load_file
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path} (the reference loads with use_safetensors=True)")
+    sd: Dict[str, torch.Tensor] = {}
+    for f in files:
+        sd.update(load_file(f))
+    return sd
+
+
+def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, switch_depth: int = 2, **cap) -> OpusConfig:
+    """HF Llama config.json + the reference's hard-coded protein dims -> OpusConfig."""
+    H, nh = hf_cfg["hidden_size"], hf_cfg["num_attention_heads"]
+    rope = hf_cfg.get("rope_theta") or (hf_cfg.get("rope_parameters") or {}).get("rope_theta", 10000.0)
+    if hf_cfg.get("rope_scaling"):
+        raise NotImplementedError("rope_scaling is not built (Llama-3-8B and Vicuna use plain rotary)")
+    return OpusConfig(**esm2_dims(esm), proj_dim=proj_dim, switch_depth=switch_depth,
+                      dec_layers=hf_cfg["num_hidden_layers"], dec_dim=H, dec_heads=nh,
+                      dec_kv_heads=hf_cfg.get("num_key_value_heads", nh), dec_head_dim=hf_cfg.get("head_dim") or H // nh,
+                      dec_ffn=hf_cfg["intermediate_size"], dec_vocab=hf_cfg["vocab_size"],
+                      dec_rms_eps=hf_cfg.get("rms_norm_eps", 1e-5), dec_rope_theta=float(rope), **cap).validate()
+
+
+def canonical_from_hf_llama(sd: Dict[str, torch.Tensor], cfg: OpusConfig) -> Dict[str, torch.Tensor]:
+    out = {"dec.embed_tokens": sd["model.embed_tokens.weight"], "dec.norm.weight": sd["model.norm.weight"],
+           "dec.lm_head.weight": sd.get("lm_head.weight", sd["model.embed_tokens.weight"])}
+    for l in range(cfg.dec_layers):
+        s, d = f"model.layers.{l}.", f"dec.layers.{l}."
+        out[d + "input_norm.weight"] = sd[s + "input_layernorm.weight"]
+        out[d + "post_norm.weight"] = sd[s + "post_attention_layernorm.weight"]
+        for a in ("q", "k", "v", "o"):
+            out[d + a + ".weight"] = sd[s + f"self_attn.{a}_proj.weight"]
+        for a in ("gate", "up", "down"):
+            out[d + a + ".weight"] = sd[s + f"mlp.{a}_proj.weight"]
+    return out
+
+
+def canonical_from_esm2(sd: Dict[str, torch.Tensor], cfg: OpusConfig) -> Dict[str, torch.Tensor]:
+    """fair_esm ESM2 state dict (hub checkpoint 'model' entry; 'encoder.sentence_encoder.' prefix optional)."""
+    def strip(k):
+        for p in ("encoder.sentence_encoder.", "encoder.", "sentence_encoder."):
+            if k.startswith(p):
+                return k[len(p):]
+        return k
+    sd = {strip(k): v for k, v in sd.items()}
+    out = {"enc.embed_tokens": sd["embed_tokens.weight"],
+           "enc.ln_f.weight": sd["emb_layer_norm_after.weight"], "enc.ln_f.bias": sd["emb_layer_norm_after.bias"]}
+    for l in range(cfg.enc_layers):
+        s, d = f"layers.{l}.", f"enc.layers.{l}."
+        for a, b in (("ln1", "self_attn_layer_norm"), ("q", "self_attn.q_proj"), ("k", "self_attn.k_proj"),
+                     ("v", "self_attn.v_proj"), ("o", "self_attn.out_proj"), ("ln2", "final_layer_norm"),
+                     ("fc1", "fc1"), ("fc2", "fc2")):
+            out[d + a + ".weight"] = sd[s + b + ".weight"]
+            out[d + a + ".bias"] = sd[s + b + ".bias"]
+    return out
+
+
+def canonical_from_cstp(ckpt: dict) -> Dict[str, torch.Tensor]:
+    sd = ckpt.get("state_dict", ckpt)
+    return {"proj.weight": sd["protein_projection.linear.weight"], "proj.bias": sd["protein_projection.linear.bias"]}
+
+
+def canonical_from_switch(sd: Dict[str, torch.Tensor], depth: int) -> Dict[str, torch.Tensor]:
+    """Keys after 'switch_projector.' (opus_arch.py:86-89); nn.Sequential indices 0,2,4,... are the Linears."""
+    w = {k.split("switch_projector.")[1]: v for k, v in sd.items() if "switch_projector" in k}
+    if depth == 1 and "weight" in w:
+        return {"switch.0.weight": w["weight"], "switch.0.bias": w["bias"]}
+    return {f"switch.{i}.{p}": w[f"{2 * i}.{p}"] for i in range(depth) for p in ("weight", "bias")}
+
+
+def lora_from_peft(adapter_dir: str, cfg: OpusConfig) -> Dict[str, Tuple[torch.Tensor, torch.Tensor, float, int]]:
+    """PEFT adapter -> {canonical weight name: (A, B, alpha, r)} for the decoder projections it targets."""
+    with open(os.path.join(adapter_dir, "adapter_config.json")) as f:
+        ac = json.load(f)
+    r, alpha = int(ac["r"]), float(ac["lora_alpha"])
+    st = os.path.join(adapter_dir, "adapter_model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    else:
+        sd = torch.load(os.path.join(adapter_dir, "adapter_model.bin"), map_location="cpu", weights_only=True)
+    names = {"q_proj": "q", "k_proj": "k", "v_proj": "v", "o_proj": "o", "gate_proj": "gate", "up_proj": "up", "down_proj": "down"}
+    out = {}
+    for k, A in sd.items():
+        if "lora_A" not in k:
+            continue
+        parts = k.split(".")
+        l = int(parts[parts.index("layers") + 1])
+        mod = next((names[p] for p in parts if p in names), None)
+        if mod is None:
+            raise NotImplementedError(f"LoRA target outside the decoder projections: {k}")
+        out[f"dec.layers.{l}.{mod}.weight"] = (A, sd[k.replace("lora_A", "lora_B")], alpha, r)
+    return out
+
+
+def _esm2_ckpt_path() -> str:
+    p = os.environ.get("OPUS_ESM2_CKPT") or os.path.expanduser("~/.cache/torch/hub/checkpoints/esm2_t33_650M_UR50D.pt")
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"ESM-2 checkpoint not found at {p}: set OPUS_ESM2_CKPT (the reference downloads it through "
+                                "esm.pretrained.esm2_t33_650M_UR50D(), cstp_v3/modelling.py:21; no download is attempted here)")
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ entry point
+def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=False, load_4bit=False, accelerator=None,
+                          switch_projector_type="mlp2x_gelu", cstp_path=True, **kwargs):
+    """-> (tokenizer, model, context_len), as model/builder.py:29-131.
+
+    Extra keyword arguments (all optional): device, max_batch, max_enc_tokens, max_prompt, max_new_tokens (context
+    capacity), seed (synthetic presets).  load_4bit / load_8bit select bitsandbytes quantisation in the reference (a
+    CUDA-only library, out of scope): the weights are loaded unquantised in fp16 and a warning says so.
+    """
+    if load_8bit or load_4bit:
+        warnings.warn("NF4 / int8 loading is not built for MI355X (bitsandbytes is CUDA-only): loading unquantised fp16")
+    rank = accelerator.process_index if accelerator is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(kwargs.pop("device", f"cuda:{rank}"))
+    cap = {k: kwargs.pop(k) for k in ("max_batch", "max_enc_tokens", "max_prompt", "max_new_tokens") if k in kwargs}
+    depth = switch_depth_from_type(switch_projector_type)
+    if not (model_name is not None and model_base_path):
+        raise NotImplementedError
+
+    if str(model_base_path).startswith("synthetic:"):
+        cfg = PRESETS[model_base_path.split(":", 1)[1]](switch_depth=depth, **cap)
+        weights = DeviceWeights.synthetic(cfg, int(kwargs.pop("seed", 0)), device)
+        tokenizer = SyntheticTokenizer(cfg.dec_vocab)
+        model = OpusLlamaForCausalLM(cfg, weights, device, eos_token_id=tokenizer.eos_token_id,
+                                     pad_token_id=tokenizer.pad_token_id)
+        return tokenizer, model, 512
+
+    low = model_base_path.lower()
+    if "llama" not in low and "vicuna" not in low:
+        # the reference also dispatches on 'opt'/'galactica'/'qwen' (builder.py:71-96): other decoder families
+        raise NotImplementedError("only the Llama decoder family is built (SURVEY 8f N4)")
+    with open(os.path.join(model_base_path, "config.json")) as f:
+        hf_cfg = json.load(f)
+    cfg = config_from_hf(hf_cfg, switch_depth=depth, **cap)
+    canon = canonical_from_hf_llama(_load_safetensors_dir(model_base_path), cfg)
+    import transformers
+    tokenizer = transformers.AutoTokenizer.from_pretrained(model_base_path, use_fast=False)
+    tokenizer.pad_token = tokenizer.unk_token = tokenizer.eos_token
+    tokenizer.pad_token_id = tokenizer.unk_token_id = tokenizer.eos_token_id
+    if accelerator is not None:
+        accelerator.wait_for_everyone()
+    lora = None
+    if adapter_path is not None:
+        lora = lora_from_peft(return_cstp_path(adapter_path, "lora_adapter"), cfg)
+        sw = torch.load(return_cstp_path(adapter_path, "modality_refinement_projector/modality_refinement_projection.bin"),
+                        map_location="cpu", weights_only=True)
+        canon.update(canonical_from_switch(sw, depth))
+    else:
+        print("No adapter path!")
+    if isinstance(cstp_path, str):
+        canon.update(canonical_from_cstp(torch.load(cstp_path, map_location="cpu", weights_only=False)))
+    else:
+        raise NotImplementedError("the identity protein projector (no CSTP checkpoint, opus_arch.py:70-80) is not built")
+    esm = torch.load(_esm2_ckpt_path(), map_location="cpu", weights_only=False)
+    canon.update(canonical_from_esm2(esm.get("model", esm), cfg))
+    weights = DeviceWeights.from_canonical(cfg, canon, device, lora=lora)
+    eos = hf_cfg.get("eos_token_id", tokenizer.eos_token_id)
+    model = OpusLlamaForCausalLM(cfg, weights, device, eos_token_id=eos, pad_token_id=tokenizer.pad_token_id)
+    context_len = hf_cfg.get("max_sequence_length", 512)     # builder.py:126-129
+    return tokenizer, model, context_len

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -671,7 +672,8 @@ extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uin
     HIPC(hipMemsetAsync(c->d_nunf, 0, (size_t)max_new * sizeof(int32_t), s));
     OPC(prefill(c, s, (const half_t *)d_embeds, d_mask, B, T));
 
-    const bool use_graph = s != nullptr && !c->timing;
+    // OPUS_NO_GRAPH=1: eager launches (rocprofv3 --pmc cannot collect counters through graph replays)
+    const bool use_graph = s != nullptr && !c->timing && !getenv("OPUS_NO_GRAPH");
     auto graph_matches = [&]() {
         return c->gexec && c->g_B == B && c->g_T == T && c->g_maxnew == max_new && c->g_pad == pad_id &&
                c->g_neos == n_eos && c->g_out == d_out_ids;

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Batch annotation driver: the MI355X-native counterpart of eval/run_opus_ddp.py (same flags, same flow).
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+      opus-pllm_amd/eval_ddp.py --model-base-path <hf dir | synthetic:llama3_8b> \\
+      --opus-pllm-weights-path <adapter dir> --input_path data.json --save_path out.json
+
+Flow (run_opus_ddp.py:47-148): load -> read JSON -> contiguous split over ranks -> batches of 8 -> prompt ->
+tokenizer_seq_token -> left-pad -> generate -> decode, cut at '###' -> gather in rank order -> rank 0 saves.
+Differences, all deliberate: greedy decode is the default (sampling is row N1), the gather moves token ids
+(int tensor all-gather over RCCL) instead of pickled strings, task metrics (metrics_computing_opi.py) are not run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import opus_pllm_amd as opa                                                    # noqa: E402
+from opus_pllm_amd import dist as odist                                        # noqa: E402
+from opus_pllm_amd.builder import load_pretrained_model, return_cstp_path      # noqa: E402
+from opus_pllm_amd.prompt import after_process_output, build_prompt, max_new_tokens_for   # noqa: E402
+
+
+def eval_model(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    model_name = opa.get_model_name_from_path(args.model_base_path)
+    cstp_path = return_cstp_path(args.opus_pllm_weights_path, "modality_encoder/modality_encoding_adapter.ckpt")
+    tokenizer, model, _ = load_pretrained_model(args.model_base_path, args.opus_pllm_weights_path, model_name,
+                                                args.load_8bit, args.load_4bit, switch_projector_type=args.switch_projector_type,
+                                                cstp_path=cstp_path, device=f"cuda:{local}", max_batch=args.batch_size,
+                                                max_enc_tokens=args.max_residues + 2, max_prompt=args.max_prompt,
+                                                max_new_tokens=256)
+    qs = [q for q in json.load(open(args.input_path)) if q["input"] is not None]
+    n = len(qs)
+    lo, hi = odist.shard_bounds(n, rank, world)
+    mine = qs[lo:hi]
+    max_new = max_new_tokens_for(args.input_path) if args.max_new_tokens is None else args.max_new_tokens
+    dev = torch.device("cuda", local)
+    outs = []
+    t0 = time.time()
+    for i in range(0, len(mine), args.batch_size):
+        batch = mine[i:i + args.batch_size]
+        prompts = [build_prompt(q["instruction"], args.input_path) for q in batch]
+        ids = [opa.tokenizer_seq_token(p, tokenizer, opa.DEFAULT_SEQ_TOKEN_INDEX, return_tensors="pt").to(dev) for p in prompts]
+        ids = opa.left_pad_sequence(ids, padding_value=tokenizer.pad_token_id, batch_first=True)
+        mask = ids != tokenizer.pad_token_id
+        with torch.inference_mode():
+            out = model.generate(ids, [q["input"] for q in batch], attention_mask=mask, pad_token_id=tokenizer.eos_token_id,
+                                 do_sample=args.temperature > 0, temperature=args.temperature, top_p=args.top_p,
+                                 num_beams=args.num_beams, max_new_tokens=max_new, use_cache=True)
+        full = torch.full((out.shape[0], max_new), tokenizer.eos_token_id, dtype=torch.long, device=dev)
+        full[:, : out.shape[1]] = out
+        outs.append(full)
+    local_ids = torch.cat(outs) if outs else torch.empty((0, max_new), dtype=torch.long, device=dev)
+    all_ids = odist.all_gather_ids(local_ids, tokenizer.eos_token_id)
+    if rank == 0:
+        dt = time.time() - t0
+        texts = [after_process_output(t) for t in tokenizer.batch_decode(all_ids, skip_special_tokens=True)]
+        result = [{"ground_truth": q["output"], "generated": t} for q, t in zip(qs, texts)]
+        print(f"entries/sec: {n / dt}, time elapsed: {dt}")
+        with open(args.save_path, "w") as f:
+            json.dump(result, f)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("--model-base-path", type=str, default="synthetic:c1_tiny")
+    p.add_argument("--opus-pllm-weights-path", type=str, default="synthetic")
+    p.add_argument("--input_path", type=str, required=True)
+    p.add_argument("--save_path", type=str, required=True)
+    p.add_argument("--temperature", type=float, default=0.0)
+    p.add_argument("--top_p", type=float, default=0.7)
+    p.add_argument("--num_beams", type=int, default=1)
+    p.add_argument("--max_new_tokens", type=int, default=None)
+    p.add_argument("--switch_projector_type", type=str, default="mlp2x_gelu")
+    p.add_argument("--load-4bit", action="store_true")
+    p.add_argument("--load-8bit", action="store_true")
+    p.add_argument("--batch_size", type=int, default=8)          # hard-coded 8 in the reference (:75)
+    p.add_argument("--max_residues", type=int, default=1024)
+    p.add_argument("--max_prompt", type=int, default=256)
+    eval_model(p.parse_args())

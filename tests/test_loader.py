@@ -1,0 +1,155 @@
+"""Row W1: the four checkpoint artefacts + ESM-2 hub checkpoint -> canonical tensors -> model.
+CPU part: name mapping and prompt assembly.  GPU part: files written in the reference's layouts load into a
+model that generates the same ids as one built directly from the canonical tensors (LoRA merged)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import opus_pllm_amd as opa
+from opus_pllm_amd import builder, synth
+from opus_pllm_amd.prompt import after_process_output, build_prompt, conv_vicuna_v0, max_new_tokens_for
+from fake_tokenizer import FakeTokenizer
+
+
+def _write_artefacts(root, cfg, canon, lora_r=4, lora_alpha=8.0):
+    from safetensors.torch import save_file
+    t = lambda n: torch.from_numpy(canon[n]).half().contiguous()                   # noqa: E731
+    base = os.path.join(root, "tiny-llama")
+    adapter = os.path.join(root, "adapter")
+    os.makedirs(base)
+    for d in ("lora_adapter", "modality_refinement_projector", "modality_encoder"):
+        os.makedirs(os.path.join(adapter, d))
+    hf = {"model.embed_tokens.weight": t("dec.embed_tokens"), "model.norm.weight": t("dec.norm.weight"),
+          "lm_head.weight": t("dec.lm_head.weight")}
+    for l in range(cfg.dec_layers):
+        s, d = f"dec.layers.{l}.", f"model.layers.{l}."
+        hf[d + "input_layernorm.weight"] = t(s + "input_norm.weight")
+        hf[d + "post_attention_layernorm.weight"] = t(s + "post_norm.weight")
+        for a in ("q", "k", "v", "o"):
+            hf[d + f"self_attn.{a}_proj.weight"] = t(s + a + ".weight")
+        for a in ("gate", "up", "down"):
+            hf[d + f"mlp.{a}_proj.weight"] = t(s + a + ".weight")
+    save_file(hf, os.path.join(base, "model.safetensors"))
+    json.dump(dict(hidden_size=cfg.dec_dim, num_attention_heads=cfg.dec_heads, num_key_value_heads=cfg.dec_kv_heads,
+                   head_dim=cfg.dec_head_dim, num_hidden_layers=cfg.dec_layers, intermediate_size=cfg.dec_ffn,
+                   vocab_size=cfg.dec_vocab, rms_norm_eps=cfg.dec_rms_eps, rope_theta=cfg.dec_rope_theta,
+                   eos_token_id=2), open(os.path.join(base, "config.json"), "w"))
+    g = torch.Generator().manual_seed(3)
+    lora, sd = {}, {}
+    for l, mod, cname in ((0, "q_proj", "q"), (1, "v_proj", "v"), (1, "down_proj", "down")):
+        W = canon[f"dec.layers.{l}.{cname}.weight"]
+        A = (torch.randn(lora_r, W.shape[1], generator=g) * 0.1).half()
+        B = (torch.randn(W.shape[0], lora_r, generator=g) * 0.1).half()
+        grp = "self_attn" if mod != "down_proj" else "mlp"
+        sd[f"base_model.model.model.layers.{l}.{grp}.{mod}.lora_A.weight"] = A
+        sd[f"base_model.model.model.layers.{l}.{grp}.{mod}.lora_B.weight"] = B
+        lora[f"dec.layers.{l}.{cname}.weight"] = (A, B, lora_alpha, lora_r)
+    save_file(sd, os.path.join(adapter, "lora_adapter", "adapter_model.safetensors"))
+    json.dump(dict(r=lora_r, lora_alpha=lora_alpha, target_modules=["q_proj", "v_proj", "down_proj"]),
+              open(os.path.join(adapter, "lora_adapter", "adapter_config.json"), "w"))
+    torch.save({f"model.switch_projector.{2 * i}.{p}": torch.from_numpy(canon[f"switch.{i}.{p}"])
+                for i in range(cfg.switch_depth) for p in ("weight", "bias")},
+               os.path.join(adapter, "modality_refinement_projector", "modality_refinement_projection.bin"))
+    torch.save({"state_dict": {"protein_projection.linear.weight": torch.from_numpy(canon["proj.weight"]),
+                               "protein_projection.linear.bias": torch.from_numpy(canon["proj.bias"]),
+                               "text_projection.linear.weight": torch.zeros(2, 2)}},
+               os.path.join(adapter, "modality_encoder", "modality_encoding_adapter.ckpt"))
+    esm = {"encoder.sentence_encoder.embed_tokens.weight": torch.from_numpy(canon["enc.embed_tokens"]),
+           "encoder.sentence_encoder.emb_layer_norm_after.weight": torch.from_numpy(canon["enc.ln_f.weight"]),
+           "encoder.sentence_encoder.emb_layer_norm_after.bias": torch.from_numpy(canon["enc.ln_f.bias"])}
+    for l in range(cfg.enc_layers):
+        for a, b in (("ln1", "self_attn_layer_norm"), ("q", "self_attn.q_proj"), ("k", "self_attn.k_proj"),
+                     ("v", "self_attn.v_proj"), ("o", "self_attn.out_proj"), ("ln2", "final_layer_norm"),
+                     ("fc1", "fc1"), ("fc2", "fc2")):
+            for p in ("weight", "bias"):
+                esm[f"encoder.sentence_encoder.layers.{l}.{b}.{p}"] = torch.from_numpy(canon[f"enc.layers.{l}.{a}.{p}"])
+    esm_path = os.path.join(root, "esm2.pt")
+    torch.save({"model": esm, "cfg": {}}, esm_path)
+    return base, adapter, esm_path, lora
+
+
+def test_canonical_mappings_roundtrip(tmp_path):
+    cfg = opa.micro()
+    canon = synth.canonical_weights(cfg, 0)
+    base, adapter, esm_path, lora = _write_artefacts(str(tmp_path), cfg, canon)
+    hf_cfg = json.load(open(os.path.join(base, "config.json")))
+    c2 = builder.config_from_hf(hf_cfg)
+    assert (c2.dec_dim, c2.dec_kv_heads, c2.dec_head_dim, c2.dec_vocab, c2.enc_dim) == (64, 2, 16, 96, 1280)
+    got = builder.canonical_from_hf_llama(builder._load_safetensors_dir(base), cfg)
+    got.update(builder.canonical_from_esm2(torch.load(esm_path, weights_only=False)["model"], cfg))
+    got.update(builder.canonical_from_cstp(torch.load(os.path.join(adapter, "modality_encoder/modality_encoding_adapter.ckpt"),
+                                                      weights_only=False)))
+    got.update(builder.canonical_from_switch(torch.load(
+        os.path.join(adapter, "modality_refinement_projector/modality_refinement_projection.bin"), weights_only=True), cfg.switch_depth))
+    assert set(got) == set(canon)
+    for k in canon:
+        assert np.array_equal(got[k].float().numpy(), canon[k]), k
+    lo = builder.lora_from_peft(os.path.join(adapter, "lora_adapter"), cfg)
+    assert set(lo) == set(lora) and all(lo[k][2:] == (8.0, 4) for k in lo)
+    assert builder.return_cstp_path("a/", "b") == "a/b" and builder.return_cstp_path("a", "b") == "a/b"
+
+
+def test_prompt_assembly_matches_reference_format():
+    p = build_prompt("What is the function?", "data/function.json")
+    assert p == (conv_vicuna_v0.system + "\n\n### Student: <seq>\nWhat is the function?\n### Professor:")
+    assert build_prompt("Where?", "x/subcell_localization.json").endswith("<seq>\nWhere?Kindly reply with only one word.\n### Professor:")
+    assert build_prompt("keep <seq> here", "").count("<seq>") == 1
+    assert (max_new_tokens_for("a/localization.json"), max_new_tokens_for("keywords.json"), max_new_tokens_for("x.json")) == (32, 128, 256)
+    assert after_process_output("  Nucleus ### Student: more") == "Nucleus" and after_process_output("abc") == "abc"
+    ids = opa.tokenizer_seq_token(p, FakeTokenizer())
+    assert ids.count(-200) == 1 and ids[0] == 1
+
+
+def test_missing_artefacts_fail_without_network(tmp_path, monkeypatch):
+    monkeypatch.setenv("OPUS_ESM2_CKPT", str(tmp_path / "nope.pt"))
+    with pytest.raises(FileNotFoundError):
+        builder._esm2_ckpt_path()
+    with pytest.raises(NotImplementedError):
+        builder.load_pretrained_model("/models/opt-350m", None, "opt", device="cuda:0")
+
+
+@pytest.mark.gpu
+def test_load_pretrained_model_from_files(tmp_path, monkeypatch):
+    import transformers
+    from opus_pllm_amd.model import OpusLlamaForCausalLM
+    from opus_pllm_amd.weights import DeviceWeights
+    cfg0 = opa.micro()
+    canon = synth.canonical_weights(cfg0, 0)
+    base, adapter, esm_path, lora = _write_artefacts(str(tmp_path), cfg0, canon)
+    monkeypatch.setenv("OPUS_ESM2_CKPT", esm_path)
+    monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", staticmethod(lambda *a, **k: FakeTokenizer()))
+    monkeypatch.setattr(builder, "esm2_dims", lambda name: dict(enc_layers=2, enc_dim=64, enc_heads=4, enc_ffn=256))
+    cap = dict(max_batch=8, max_enc_tokens=66, max_prompt=48, max_new_tokens=16)
+    monkeypatch.setattr(builder, "config_from_hf", lambda hf, **kw: opa.micro(**{k: v for k, v in kw.items() if k in cap}))
+    with pytest.warns(UserWarning):
+        tok, model, ctx_len = builder.load_pretrained_model(
+            base, adapter, "tiny-llama", load_4bit=True, cstp_path=builder.return_cstp_path(adapter, "modality_encoder/modality_encoding_adapter.ckpt"),
+            device="cuda:0", **cap)
+    assert ctx_len == 512 and tok.pad_token_id == tok.eos_token_id
+    dev = torch.device("cuda:0")
+    ref = OpusLlamaForCausalLM(cfg0, DeviceWeights.from_canonical(cfg0, canon, dev, lora=lora), dev)
+    for k, v in ref.weights.tensors.items():
+        assert torch.equal(v, model.weights.tensors[k]), k
+    ids = torch.tensor([synth.synth_prompt_ids(cfg0.dec_vocab, 0, n_text=12, seq_pos=4)])
+    a = model.generate(ids, [synth.synth_protein(30, 0)], max_new_tokens=6, pad_token_id=2)
+    b = ref.generate(ids, [synth.synth_protein(30, 0)], max_new_tokens=6, pad_token_id=2)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_synthetic_preset_loader_and_batch8():
+    tok, model, _ = builder.load_pretrained_model("synthetic:micro", "synthetic", "micro", device="cuda:0", max_prompt=96)
+    prompts = [build_prompt(f"describe protein number {i}", "") for i in range(8)]
+    ids = [opa.tokenizer_seq_token(p, tok, return_tensors="pt") for p in prompts]
+    ids = opa.left_pad_sequence(ids, tok.pad_token_id, batch_first=True)
+    assert ids.shape[1] + 7 <= 96
+    seqs = [synth.synth_protein(10 + 5 * i, i) for i in range(8)]
+    out = model.generate(ids, seqs, attention_mask=ids != tok.pad_token_id, pad_token_id=tok.eos_token_id, max_new_tokens=5)
+    assert out.shape == (8, 5) and out.dtype == torch.long
+    # batch invariance: row 3 alone gives the same ids
+    one = model.generate(ids[3:4], seqs[3:4], attention_mask=(ids != tok.pad_token_id)[3:4], pad_token_id=tok.eos_token_id,
+                         max_new_tokens=5)
+    assert torch.equal(one[0], out[3])

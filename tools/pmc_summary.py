@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes of bench.py into profiles/<tag>_pmc_traffic.json.
+
+  python tools/pmc_summary.py <read_pass_dir> <write_pass_dir> <out.json> [steps_in_run]
+
+Read pass:  --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum   (the FETCH_SIZE derived counter segfaults
+            rocprofv3 on this ROCm 7.2 image; its definition is built from these request counters)
+Write pass: --pmc WRITE_SIZE                                 (KiB, exact for 16-B stores)
+gfx950 correction (MI355X_MICROARCH.md "HBM"): the read-request counter tallies the 128-B requests of a
+wide coalesced stream at 64 B, i.e. FETCH_SIZE reads exactly half of the bytes -> bytes = requests * 128
+for the non-32B requests.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[(name, r["Counter_Name"])] += 1
+    return agg, cnt
+
+
+def main():
+    rd, rcnt = load(sys.argv[1])
+    wr, _ = load(sys.argv[2])
+    out = {}
+    for name, c in rd.items():
+        req, r32 = c.get("TCC_EA0_RDREQ_sum", 0.0), c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        n = rcnt[(name, "TCC_EA0_RDREQ_sum")]
+        fetch = (req - r32) * 128 + r32 * 32
+        write = wr.get(name, {}).get("WRITE_SIZE", 0.0) * 1024
+        out[name] = {"launches": n, "fetch_bytes": fetch, "write_bytes": write,
+                     "hbm_bytes_per_launch": (fetch + write) / max(n, 1)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["fetch_bytes"])[:8]:
+        print(f"{k[:70]:70s} launches={v['launches']:6d} HBM/launch={v['hbm_bytes_per_launch']/1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
