@@ -65,6 +65,19 @@ def parse():
     return p.parse_args()
 
 
+def pmc_traffic():
+    """Average HBM bytes per gemm_skinny launch from the committed rocprofv3 PMC passes of this command
+    (tools/pmc_summary.py -> profiles/*_pmc_traffic.json; bench.py cannot run the profiler itself)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    rows = [v for k, v in d.items() if "gemm_skinny_kernel" in k]
+    n = sum(v["launches"] for v in rows)
+    return sum(v["fetch_bytes"] + v["write_bytes"] for v in rows) / n if n else None
+
+
 def cpu_baseline(cfg, residues, n_text, n_new):
     """The oracle (CPU fp32 port of the reference path) timed on this host's cores on a bounded sample:
     one protein through the full-depth encoder + projectors + full-depth prefill + 4 decode steps,
@@ -214,7 +227,8 @@ def main():
         model.timing(False)
         res["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny_kernel (weight-streaming GEMM, M<=64)",
                            "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                           "algorithmic_bytes_per_launch": by / max(n, 1),
                            "launches_per_step": n, "avg_launch_us": 1e3 * ms / max(n, 1),
                            "algorithmic_bytes_per_step": by,
                            "event_ms_per_step": {"skinny_gemm": ms, **{k: v[0] for k, v in parts.items()}}}
