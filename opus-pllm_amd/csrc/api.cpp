@@ -368,7 +368,7 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
                          (residual ? 4.0 * M * nout : 0.0);
-    int klass = M <= 64 ? KC_SKINNY : KC_TILE;
+    int klass = M <= SKINNY_MAX_M ? KC_SKINNY : KC_TILE;
     Timed t(c, s, klass, bytes);
     hipError_t e = launch_gemm(p, s, &klass);
     if (e != hipSuccess) return fail(OPUS_EHIP, "gemm M=%d N=%d K=%d failed: %s", M, N, K, hipGetErrorString(e));
@@ -389,7 +389,7 @@ static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const 
 // otherwise a weight-less rmsnorm kernel into `scratch` followed by the tile kernel.
 static int gemm_norm(opus_ctx *c, hipStream_t s, const float *X, float eps, half_t *scratch, const half_t *W, int M, int N,
                      int K, int epi, void *C, int64_t ldc, int out_f32) {
-    if (M <= 64) return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
+    if (M <= SKINNY_MAX_M) return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
     KL(KC_OTHER, 6.0 * M * K, launch_rmsnorm(X, nullptr, eps, M, K, scratch, s));
     return gemm(c, s, scratch, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
 }
@@ -740,7 +740,7 @@ extern "C" int opus_debug_gemm(opus_ctx *c, const void *A, const void *W, const 
 extern "C" int opus_debug_gemm_norm(opus_ctx *c, const float *A, const void *W, void *Cp, int32_t M, int32_t N, int32_t K,
                                     int32_t epi, int32_t out_f32, float eps, void *stream) {
     if (!c || !A || !W || !Cp) return fail(OPUS_EBADARG, "debug_gemm_norm: null pointer");
-    if (M < 1 || M > 64 || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_norm: M <= 64, K %% 64 == 0");
+    if (M < 1 || M > SKINNY_MAX_M || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_norm: M <= 16, K %% 64 == 0");
     if (epi != 0 && epi != 2) return fail(OPUS_EBADARG, "debug_gemm_norm: epilogue 0 or 2");
     HIPC(hipSetDevice(c->device));
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;

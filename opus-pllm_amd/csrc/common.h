@@ -12,6 +12,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
+// M up to which the weight-streaming skinny kernel is used (LDS-staged activations, fused RMSNorm);
+// above it the LDS-tiled MFMA kernel (with split-K when the output has few tiles) streams the weights.
+constexpr int SKINNY_MAX_M = 16;
 enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_COUNT = 5 };
 
 // C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.

@@ -17,6 +17,7 @@
 //  * gemm_tile (M > 64): 128x128x64 LDS-tiled MFMA kernel (4 waves x 64x64), register-staged double
 //    buffering; A image XOR-swizzled, B image kept in fragment order (linear ds_read_b128).
 #include "common.h"
+#include <cstdlib>
 
 namespace opus {
 
@@ -434,6 +435,8 @@ static hipError_t launch_skinny_t(const GemmParams &p, hipStream_t s) {
     // workgroups tile the CU), the smallest that puts >= ~3000 waves on the chip (tools/bench_skinny.hip:
     // the stream saturates from ~8 waves per CU), never more k-parts than 64-wide chunks.
     int W = (int64_t)groups * 4 >= 3000 ? 4 : ((int64_t)groups * 8 >= 3000 ? 8 : 16);
+    static const int w_override = getenv("OPUS_SKINNY_W") ? atoi(getenv("OPUS_SKINNY_W")) : 0;   // tuning aid
+    if (w_override >= PB) W = w_override;
     while (W > PB && (W / PB > chunks || (size_t)W * MT * 272 * sizeof(float) > 48 * 1024)) W >>= 1;
     int wpp = W / PB;
     if (wpp < 1) wpp = 1;
@@ -526,7 +529,7 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 63) || (p.lda & 7)) return hipErrorInvalidValue;
     if (p.epi == EPI_SILU_GU16 && (p.N & 31)) return hipErrorInvalidValue;
-    const bool skinny = p.M <= 64;
+    const bool skinny = p.M <= SKINNY_MAX_M;
     if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;
     if (p.Af && !skinny) return hipErrorInvalidValue;   // fused norm exists in the skinny kernel only
     if (skinny) {

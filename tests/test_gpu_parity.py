@@ -223,6 +223,23 @@ def test_splice_golden_bit_exact(micro, gold, tag):
         assert np.array_equal(mo.bool().cpu().numpy(), g[tag + ".mask_out"].astype(bool))
 
 
+def test_prepare_inputs_labels_golden(micro, gold):
+    """The full reference method incl. label bookkeeping (training-side right padding) vs the golden."""
+    cfg, model, W = micro
+    g = gold("splice")
+    tag = "right_pad_labels"
+    ids = torch.from_numpy(g[tag + ".ids"])
+    mask = torch.from_numpy(g[tag + ".mask_in"])
+    labels = torch.where(ids == -200, torch.full_like(ids, -100), ids)
+    n_prot = g[tag + ".pooled"].shape[0]
+    res = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, labels, ["X"] * n_prot,
+                                                     seq_embedding=torch.from_numpy(g[tag + ".pooled"]), inference_mode=False)
+    assert res[0] is None and res[1] is None and res[3] is None
+    assert np.array_equal(res[2].cpu().numpy(), g[tag + ".mask_out"]) and res[2].dtype == mask.dtype
+    assert np.array_equal(res[5].cpu().numpy(), g[tag + ".labels"])
+    assert rel_l2(res[4].float(), torch.from_numpy(g[tag + ".embeds"])) < REL_L2
+
+
 def test_splice_errors(micro):
     from opus_pllm_amd._cabi import OpusError
     cfg, model, _ = micro

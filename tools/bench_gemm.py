@@ -52,6 +52,13 @@ def bench(name, M, N, K, epi, norm, data="rand", iters=None):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "decode":
+        bench("wgu silu+norm", 1, 28672, 4096, 2, True)
+        bench("wqkv norm", 1, 6144, 4096, 0, True)
+        bench("wo", 1, 4096, 4096, 0, False)
+        bench("wd", 1, 4096, 14336, 0, False)
+        bench("lm_head norm", 1, 128256, 4096, 0, True)
+        sys.exit(0)
     for data in ("const", "rand"):
         bench("wgu plain", 1, 28672, 4096, 0, False, data)
         bench("wgu silu", 1, 28672, 4096, 2, False, data)
