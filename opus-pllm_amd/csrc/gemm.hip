@@ -277,6 +277,51 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
         }
 }
 
+// Epilogue for accumulators computed as C^T tiles (weights as the MFMA A operand, activations as B):
+// lane (li, g) holds C[m = li][n = 4g + r], r = 0..3, i.e. FOUR CONSECUTIVE COLUMNS of one row, so bias /
+// residual / output move as one 16-B (fp32) or 8-B (fp16) access per lane instead of four scalar ones.
+template <int EPI>
+__device__ __forceinline__ void store4(const GemmParams &p, int m, int nb, f4 v, f4 up) {
+    // nb = first of the 4 columns in the GEMM's N space (for GU16: of the gate tile); up = matching up tile
+    const bool vec = ((p.ldc | p.ldr) & 3) == 0;
+    if (EPI == EPI_SILU_GU16) {
+        const int no = ((nb >> 5) << 4) + (nb & 15);          // column in the [M, N/2] output
+        if (nb + 3 < p.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float gate = v[r], u = up[r];
+                if (p.bias) { gate += p.bias[nb + r]; u += p.bias[nb + 16 + r]; }
+                v[r] = silu(gate) * u;
+            }
+        }
+        nb = no;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (p.bias && nb + r < p.N) v[r] += p.bias[nb + r];
+            if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
+        }
+    }
+    const int nlim = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
+    if (vec && nb + 3 < nlim) {
+        if (p.residual) {
+            const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nb);
+            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+        if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nb) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (nb + r >= nlim) continue;
+            float x = v[r];
+            if (p.residual) x += p.residual[(int64_t)m * p.ldr + nb + r];
+            if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + nb + r] = x;
+            else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + nb + r] = (half_t)x;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile: 128 x 128 x 64, 256 threads = 2x2 waves of 64x64 (4x4 MFMA 16x16x32 tiles each).
 // A image: [128 rows][8 chunks of 16 B], chunk c of row r at c ^ ((r>>1)&7) (conflict-free
@@ -368,7 +413,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
         }
         if (kt + 1 < kt1) lstore(buf ^ 1);
         __syncthreads();
@@ -377,52 +422,35 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
     if (ksplit > 1) {
         float *slab = p.ws + (int64_t)ks * p.M * p.N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 64 + i * 16 + 4 * g + r;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wc * 64 + j * 16 + li;
-                    if (n < p.N) slab[(int64_t)m * p.N + n] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wr * 64 + i * 16 + 4 * g + r;
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + li;
             if (m >= p.M) continue;
-            if (EPI == EPI_SILU_GU16) {
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int ng = n0 + wc * 64 + jj * 32 + li;
-                    if (ng >= p.N) continue;
-                    float gate = acc[i][2 * jj][r], up = acc[i][2 * jj + 1][r];
-                    if (p.bias) { gate += p.bias[ng]; up += p.bias[ng + 16]; }
-                    float v = silu(gate) * up;
-                    const int no = ((n0 + wc * 64 + jj * 32) >> 1) + li;
-                    if (p.residual) v += p.residual[(int64_t)m * p.ldr + no];
-                    if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
-                    else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
-                }
-            } else {
+            for (int j = 0; j < 4; ++j) {
+                const int nb = n0 + wc * 64 + j * 16 + 4 * g;
+                if ((p.N & 3) == 0 && nb + 3 < p.N) {
+                    *reinterpret_cast<float4 *>(slab + (int64_t)m * p.N + nb) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wc * 64 + j * 16 + li;
-                    if (n >= p.N) continue;
-                    float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[n];
-                    if (EPI == EPI_GELU) v = gelu_erf(v);
-                    if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
-                    if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + n] = v;
-                    else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + n] = (half_t)v;
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) slab[(int64_t)m * p.N + nb + r] = acc[i][j][r];
                 }
             }
         }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + li;
+        if (m >= p.M) continue;
+        if (EPI == EPI_SILU_GU16) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wc * 64 + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wc * 64 + j * 16 + 4 * g, acc[i][j], acc[i][j]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,6 +496,153 @@ static hipError_t launch_skinny_e(const GemmParams &p, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------------------------------------------------
+// big: 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 each = 8 x 4 MFMA tiles, 128 accumulator
+// registers), K streamed in 32-deep stages through a 4-slot LDS ring (4 x 32 KB = 128 KB) filled by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  Three stages are kept in
+// flight across the single raw s_barrier per stage with a COUNTED s_waitcnt vmcnt (never 0 in the
+// steady state): cdna_hip_programming.md "Pipelining across barriers" / T3+T4.
+//   A stage image [256 rows][4 x 16 B], the 16-B chunk c of row r stored in slot c ^ T[(r>>2)&3],
+//   T = {0,3,2,1}: conflict-free for the 16-lane groups of ds_read_b128 (rows 64 B apart).  glds
+//   writes LDS linearly, so the permutation is applied to the per-lane SOURCE address (rule 21).
+//   B stage image = the 16 weight panels' 1-KB half blocks, already in fragment order: linear.
+// Hazards: RAW - a stage is read only after every wave's vmcnt for it and the barrier; WAR - the
+// slot refilled in iteration ks was last read in iteration ks-1, and the refill is issued after the
+// barrier of iteration ks, which every wave reaches only after finishing those reads.
+constexpr int GBM = 256, GBN = 256, GBK = 32;
+
+__device__ __forceinline__ int aswz(int row) { return (-(row >> 2)) & 3; }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_big_kernel(GemmParams p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    // Grouped tile order inside each XCD's run: GM tile-rows are walked column by column, so the ~32
+    // tiles an XCD works on at one time form a compact 2-D patch (8 x 4) that shares A rows 4 ways and
+    // weight panels 8 ways in that XCD's L2, instead of a 1 x 32 strip that streams all of W per row.
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, rem_id = bid - grp * per_group;
+    const int rows_here = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;
+    const int tm = grp * GM + rem_id % rows_here, tn = rem_id / rows_here;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int KS = p.K / GBK, KT64 = p.K >> 6;
+    const int npanels = (p.N + 15) >> 4;
+
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const half_t *srcA[2], *srcB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rl = 16 * (2 * wave + j) + (lane >> 2);           // row inside the tile
+        int row = m0 + rl;
+        row = row < p.M ? row : p.M - 1;
+        srcA[j] = p.A + (int64_t)row * p.lda + (((lane & 3) ^ aswz(rl)) << 3);
+        int pn = (n0 >> 4) + 2 * wave + j;
+        pn = pn < npanels ? pn : npanels - 1;
+        srcB[j] = p.W + ((int64_t)pn * KT64) * 1024 + lane * 8;
+    }
+    constexpr int NSLOT = 4;   // 4 x 32 KB ring
+    auto stage_load = [&](int ks) {
+        char *base = smem + (ks % NSLOT) * 32768;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + (int64_t)ks * GBK), (lptr_t)(base + (2 * wave + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (int64_t)(ks >> 1) * 1024 + (ks & 1) * 512),
+                                             (lptr_t)(base + 16384 + (2 * wave + j) * 1024), 16, 0, 0);
+        }
+    };
+
+    f4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS read offsets inside a stage
+    int aoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = wm * 128 + i * 16 + li;
+        aoff[i] = rl * 64 + ((g ^ aswz(rl)) << 4);
+    }
+    const int boff = 16384 + (wn * 4) * 1024 + lane * 16;
+
+    // Schedule (one raw barrier per 32-deep stage, three stages of LDS-DMA in flight across it).
+    // Iteration ks: wait for this wave's part of stage ks+1 (stages ks+2, ks+3 stay in flight) and retire
+    // its fragment reads of stage ks -> barrier (now stage ks+1 is complete and slot ks is free) ->
+    // refill slot ks with stage ks+4 -> issue the fragment reads of stage ks+1 into the second register
+    // set -> MFMAs of stage ks (they overlap those reads).  A two-group half-stage stagger with a 5-slot
+    // ring (MI355X_MICROARCH.md "Two waves per SIMD" item 9) measured the same 1.05-1.1 PF/s and was dropped.
+    auto wait_glds = [&](int rem) {   // rem = stages issued after the one being waited for (4 glds each)
+        if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto read_frags = [&](int ks, h8 (&af)[8], h8 (&bf)[4]) {
+        const char *base = smem + (ks % NSLOT) * 32768;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const h8 *>(base + aoff[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const h8 *>(base + boff + j * 1024);
+    };
+    auto mfmas = [&](const h8 (&af)[8], const h8 (&bf)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
+        __builtin_amdgcn_s_setprio(0);
+    };
+    const int last = KS - 1;
+    auto issued_upto = [&](int x) { return x < last ? x : last; };
+    auto step = [&](int ks, const h8 (&ca)[8], const h8 (&cb)[4], h8 (&na)[8], h8 (&nb)[4]) {
+        if (ks + 1 < KS) {
+            wait_glds(issued_upto(ks + 3) - (ks + 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // WAR: this wave's reads of slot ks are done
+            __builtin_amdgcn_s_barrier();
+            if (ks + 4 < KS) stage_load(ks + 4);
+            read_frags(ks + 1, na, nb);
+        }
+        mfmas(ca, cb);
+    };
+    h8 a0[8], b0[4], a1[8], b1[4];
+    stage_load(0);
+    if (KS > 1) stage_load(1);
+    if (KS > 2) stage_load(2);
+    if (KS > 3) stage_load(3);
+    wait_glds(issued_upto(3));
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, a0, b0);
+    for (int ks = 0; ks < KS; ks += 2) {
+        step(ks, a0, b0, a1, b1);
+        if (ks + 1 < KS) step(ks + 1, a1, b1, a0, b0);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + li;
+        if (m >= p.M) continue;
+        if (EPI == EPI_SILU_GU16) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wn * 64 + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j], acc[i][j]);
+        }
+    }
+}
+
 // out[m][no] = epi(sum_ks slab[ks][m][n] + bias) (+ residual): one thread per output element.
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ksplit) {
@@ -506,6 +681,21 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         if (ea != hipSuccess) return ea;
         attr_set = true;
+    }
+    {   // enough 256 x 256 tiles to fill the chip: the 8-wave LDS-DMA pipeline
+        const int bm = cdiv(p.M, GBM), bn = cdiv(p.N, GBN);
+        static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr;   // A/B aid
+        if (!no_big && (int64_t)bm * bn >= 192) {
+            static bool big_attr = false;
+            if (!big_attr) {
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_big_kernel<EPI>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                if (ea != hipSuccess) return ea;
+                big_attr = true;
+            }
+            hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(bm * bn), dim3(512), 131072, s, p, bm, bn);
+            return hipGetLastError();
+        }
     }
     // Too few output tiles to fill 256 CUs (B = 1 prefill, single-protein encoder): split K so that
     // ~256-320 workgroups stream the weights, at least 4 k-tiles each, slabs within the workspace.

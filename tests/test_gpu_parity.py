@@ -79,6 +79,8 @@ def test_synthetic_fill_matches_numpy_twin(dev):
     (16, 512, 128, 2, 0, False), (17, 96, 192, 0, 1, True), (33, 64, 256, 1, 0, False), (64, 1024, 512, 2, 0, False),
     (65, 128, 64, 0, 0, False), (130, 384, 320, 1, 0, False), (257, 200, 128, 0, 1, True), (300, 512, 1280, 2, 0, False),
     (514, 3840, 1280, 0, 0, False), (1, 32768, 5120, 1, 0, False),
+    # >= 192 tiles of 256 x 256: the 8-wave LDS-DMA pipelined kernel (ragged M/N, 2 / 4 / 10 / 20 K stages)
+    (4100, 3000, 320, 1, 0, False), (3000, 4100, 64, 0, 1, True), (2600, 5120, 128, 2, 0, False), (3900, 3328, 640, 0, 0, False),
 ])
 def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
     """Both GEMM kernels (skinny M<=64, tile M>64), every epilogue, ragged M/N, vs fp64 on fp16 operands."""

@@ -51,7 +51,46 @@ def bench(name, M, N, K, epi, norm, data="rand", iters=None):
     print(f"{name:28s} M={M:3d} N={N:6d} K={K:6d} epi={epi} norm={int(norm)} data={data:5s}: {ms*1e3:8.2f} us  {bytes_/ms/1e6:7.0f} GB/s", flush=True)
 
 
+def bench_tile(name, M, N, K, epi, f32out=False, resid=False, iters=20):
+    W = (torch.randn(N, K, device=dev) * 0.02).half()
+    A = torch.randn(M, K, device=dev).half()
+    bias = torch.randn(N, device=dev)
+    nout = N // 2 if epi == 2 else N
+    out = torch.zeros(M, nout, dtype=torch.float32 if f32out else torch.float16, device=dev)
+    R = out if resid else None
+
+    def run():
+        _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), bias.data_ptr(), None if R is None else R.data_ptr(),
+                                        out.data_ptr(), M, N, K, epi, 1 if f32out else 0, None))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"{name:26s} M={M:6d} N={N:6d} K={K:6d} epi={epi} f32={int(f32out)} res={int(resid)}: {ms*1e3:9.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tile":
+        for M in (32896, 514):
+            bench_tile("esm qkv", M, 3840, 1280, 0)
+            bench_tile("esm wo +res", M, 1280, 1280, 0, True, True)
+            bench_tile("esm fc1 gelu", M, 5120, 1280, 1)
+            bench_tile("esm fc2 +res", M, 1280, 5120, 0, True, True)
+        for M in (6144, 96):
+            bench_tile("dec qkv", M, 6144, 4096, 0)
+            bench_tile("dec wo +res", M, 4096, 4096, 0, True, True)
+            bench_tile("dec wgu silu", M, 28672, 4096, 2)
+            bench_tile("dec wd +res", M, 4096, 14336, 0, True, True)
+        bench_tile("projector sw2 M=512", 512, 32768, 32768, 0)
+        bench_tile("square 4096", 4096, 4096, 4096, 0)
+        bench_tile("square 8192", 8192, 8192, 8192, 0)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "decode":
         bench("wgu silu+norm", 1, 28672, 4096, 2, True)
         bench("wqkv norm", 1, 6144, 4096, 0, True)
