@@ -58,6 +58,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
     half_t *kcb = kc + b * cache_sb + kvh * cache_sh;
     half_t *vcb = vc + b * cache_sb + kvh * cache_sh;
 
+    // ---- prefetch: the cached K rows of the first 128 keys (two lanes per key) and the first VP value rows of
+    // this thread's key partition are requested BEFORE the rotary / staging phase, so the three dependent
+    // global-memory round trips of the step (q/k/v row, K, V) overlap into one.
+    const int nkeys = slot - kstart + 1;
+    const int hh = tid & 1;
+    constexpr int VP = 8;
+    const int dv = tid % DV, part = tid / DV;
+    h8 kpre[HC], vpre[VP];
+    {
+        const int j = tid >> 1;
+        const int jc = j < nkeys - 1 ? j : 0;
+        const h8 *kr = reinterpret_cast<const h8 *>(kcb + (int64_t)(kstart + jc) * HD) + hh * HC;
+#pragma unroll
+        for (int c = 0; c < HC; ++c) kpre[c] = kr[c];
+#pragma unroll
+        for (int u = 0; u < VP; ++u) {
+            const int jv = part + u * PARTS;
+            const int jvc = jv < nkeys - 1 ? jv : 0;
+            vpre[u] = *reinterpret_cast<const h8 *>(vcb + (int64_t)(kstart + jvc) * HD + dv * 8);
+        }
+    }
+
     // ---- rotary on the query heads and the new key; stage k, v ----
     for (int i = tid; i < (GP + 1) * HALF; i += 256) {
         const int j = i / HALF, d = i % HALF;
@@ -85,18 +107,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
     __syncthreads();
 
     // ---- scores: two lanes per key (each half of the head dim), cached keys then the new one ----
-    const int nkeys = slot - kstart + 1;
-    const int hh = tid & 1;
     for (int j0 = 0; j0 < nkeys; j0 += 128) {
         const int j = j0 + (tid >> 1);
         float acc[GP];
 #pragma unroll
         for (int gi = 0; gi < GP; ++gi) acc[gi] = 0.f;
         if (j < nkeys - 1) {
-            const h8 *kr = reinterpret_cast<const h8 *>(kcb + (int64_t)(kstart + j) * HD) + hh * HC;
             h8 kv[HC];
+            if (j0 == 0) {
 #pragma unroll
-            for (int c = 0; c < HC; ++c) kv[c] = kr[c];
+                for (int c = 0; c < HC; ++c) kv[c] = kpre[c];
+            } else {
+                const h8 *kr = reinterpret_cast<const h8 *>(kcb + (int64_t)(kstart + j) * HD) + hh * HC;
+#pragma unroll
+                for (int c = 0; c < HC; ++c) kv[c] = kr[c];
+            }
 #pragma unroll
             for (int c = 0; c < HC; ++c)
 #pragma unroll
@@ -140,13 +165,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
     __syncthreads();
 
     // ---- O = P V : thread = (8-wide column slice, key partition) ----
-    const int dv = tid % DV, part = tid / DV;
     float acc[GP][8];
 #pragma unroll
     for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[gi][e] = 0.f;
-    for (int j = part; j < nkeys - 1; j += PARTS) {
+#pragma unroll
+    for (int u = 0; u < VP; ++u) {
+        const int j = part + u * PARTS;
+        if (j < nkeys - 1) {
+#pragma unroll
+            for (int gi = 0; gi < GP; ++gi) {
+                const float pj = sc[gi * ctx_cap + j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[gi][e] += pj * (float)vpre[u][e];
+            }
+        }
+    }
+    for (int j = part + VP * PARTS; j < nkeys - 1; j += PARTS) {
         const h8 vv = *reinterpret_cast<const h8 *>(vcb + (int64_t)(kstart + j) * HD + dv * 8);
 #pragma unroll
         for (int gi = 0; gi < GP; ++gi) {
