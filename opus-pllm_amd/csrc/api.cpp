@@ -389,7 +389,9 @@ static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const 
 // otherwise a weight-less rmsnorm kernel into `scratch` followed by the tile kernel.
 static int gemm_norm(opus_ctx *c, hipStream_t s, const float *X, float eps, half_t *scratch, const half_t *W, int M, int N,
                      int K, int epi, void *C, int64_t ldc, int out_f32) {
-    if (M <= SKINNY_MAX_M) return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
+    static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;
+    if (M <= SKINNY_MAX_M || (M <= MID_MAX_M && !no_mid))
+        return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
     KL(KC_OTHER, 6.0 * M * K, launch_rmsnorm(X, nullptr, eps, M, K, scratch, s));
     return gemm(c, s, scratch, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
 }
@@ -740,7 +742,7 @@ extern "C" int opus_debug_gemm(opus_ctx *c, const void *A, const void *W, const 
 extern "C" int opus_debug_gemm_norm(opus_ctx *c, const float *A, const void *W, void *Cp, int32_t M, int32_t N, int32_t K,
                                     int32_t epi, int32_t out_f32, float eps, void *stream) {
     if (!c || !A || !W || !Cp) return fail(OPUS_EBADARG, "debug_gemm_norm: null pointer");
-    if (M < 1 || M > SKINNY_MAX_M || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_norm: M <= 16, K %% 64 == 0");
+    if (M < 1 || M > MID_MAX_M || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_norm: M <= 128, K %% 64 == 0");
     if (epi != 0 && epi != 2) return fail(OPUS_EBADARG, "debug_gemm_norm: epilogue 0 or 2");
     HIPC(hipSetDevice(c->device));
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;

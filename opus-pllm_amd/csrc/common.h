@@ -15,6 +15,8 @@ enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
 // M up to which the weight-streaming skinny kernel is used (LDS-staged activations, fused RMSNorm);
 // above it the LDS-tiled MFMA kernel (with split-K when the output has few tiles) streams the weights.
 constexpr int SKINNY_MAX_M = 16;
+// M up to which the mid kernel (LDS-shared activations, per-wave weight stream, fused RMSNorm) is used
+constexpr int MID_MAX_M = 128;
 enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_COUNT = 5 };
 
 // C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.

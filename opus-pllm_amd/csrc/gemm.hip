@@ -21,7 +21,16 @@
 
 namespace opus {
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (nn.GELU(), fair_esm gelu): 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the fp16 rounding of the result): one v_exp + one v_rcp + 6 FMAs instead
+// of the ~40-instruction libm erff; on the 168 M activations of an ESM-2 fc1 GEMM that is 20 % of the kernel.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
@@ -497,6 +506,200 @@ static hipError_t launch_skinny_e(const GemmParams &p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// mid (16 < M <= 128: batched decode, batched projectors, B = 1 prefill).  Still a weight-streaming
+// problem (every weight byte once, HBM-bound) but with enough rows that the activations must be shared:
+// workgroup = 4 waves = 4 weight panels (64 output columns) x all M rows x one k-part.  Per 64-k chunk
+// the [M x 64] activation slice is staged once into LDS (double-buffered, XOR-swizzled; with NORM it is
+// converted from the fp32 residual stream and sum(h^2) is accumulated on the way) and read by the four
+// waves as MFMA fragments; each wave streams ITS panel straight from HBM into a 4-chunk register ring
+// (non-temporal, 8 KB in flight per wave).  Accumulators are C^T tiles (16-B epilogue accesses).
+// k-parts (gridDim.y > 1, chosen when N is too small to fill the chip) write fp32 slabs + partial
+// sum(h^2); splitk_reduce_kernel combines them in a fixed order.
+template <int MT, int EPI, bool NORM>
+__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmParams p, int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MP = 16 * MT;
+    // 64-k chunks per LDS stage (one barrier each): deeper stages pay while the fp32/fp16 staging
+    // registers still leave 2+ waves per SIMD (M <= 32); above that one chunk per stage measured faster
+    constexpr int CH = MT <= 2 ? 4 : 1;
+    constexpr int STAGE = CH * MP * 128;                             // bytes
+    float *rss = reinterpret_cast<float *>(smem + 2 * STAGE);        // [MP] sum of squares per row
+    float *xch = rss + MP;                                           // [2][MT][4][64] gate/up exchange
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int chunks = p.K >> 6;
+    const int npanels = (p.N + 15) >> 4;
+    int panel = blockIdx.x * 4 + wave;
+    const bool panel_ok = panel < npanels;
+    panel = panel_ok ? panel : npanels - 1;
+    const int ks = blockIdx.y;
+    const int c0 = (int)((int64_t)chunks * ks / ksplit), c1 = (int)((int64_t)chunks * (ks + 1) / ksplit);
+    const half_t *wp = p.W + ((int64_t)panel * chunks) * 1024 + lane * 8;
+
+    // ---- A staging of one stage (CH chunks): NORM: float4 pieces (row = q/16, col4 = q%16 inside a chunk);
+    //      else h8 pieces (row = q/8, 16-B chunk = q%8).  Pieces of chunk u are q = tid + 256 j.
+    constexpr int NP = NORM ? MT : (MT + 1) / 2;                     // pieces per thread per chunk
+    float4 af32[NORM ? CH * MT : 1];
+    h8 af16[NORM ? 1 : CH * ((MT + 1) / 2)];
+    float ssq[NORM ? MT : 1];
+#pragma unroll
+    for (int j = 0; j < (NORM ? MT : 1); ++j) ssq[j] = 0.f;
+    auto a_load = [&](int c) {                                       // chunks c .. c+CH-1 (clamped)
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int cc = c + u < c1 ? c + u : c1 - 1;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int q = tid + 256 * j;
+                if (NORM) {
+                    int row = q >> 4;
+                    row = row < p.M ? row : p.M - 1;
+                    af32[u * MT + j] = *reinterpret_cast<const float4 *>(p.Af + (int64_t)row * p.lda + (int64_t)cc * 64 + (q & 15) * 4);
+                } else if (q < MP * 8) {
+                    int row = q >> 3;
+                    row = row < p.M ? row : p.M - 1;
+                    af16[u * NP + j] = *reinterpret_cast<const h8 *>(p.A + (int64_t)row * p.lda + (int64_t)cc * 64 + (q & 7) * 8);
+                }
+            }
+        }
+    };
+    auto a_store = [&](int buf, int c) {
+        char *base = smem + buf * STAGE;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const bool live = c + u < c1;                            // clamped duplicates must not be counted twice
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int q = tid + 256 * j;
+                if (NORM) {
+                    const int row = q >> 4, c4 = q & 15;
+                    const float4 v = af32[u * MT + j];
+                    if (live) ssq[j] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    const int chunk = (c4 >> 1) ^ ((row >> 1) & 7);
+                    *reinterpret_cast<h4 *>(base + u * MP * 128 + row * 128 + chunk * 16 + (c4 & 1) * 8) =
+                        h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+                } else if (q < MP * 8) {
+                    const int row = q >> 3;
+                    *reinterpret_cast<h8 *>(base + u * MP * 128 + row * 128 + (((q & 7) ^ ((row >> 1) & 7)) << 4)) = af16[u * NP + j];
+                }
+            }
+        }
+    };
+
+    f4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    // weights: two NAMED register sets of one stage each (runtime-indexed arrays would go to scratch)
+    h8 wlA[CH], whA[CH], wlB[CH], whB[CH];
+    auto w_load = [&](h8 (&wl)[CH], h8 (&wh)[CH], int c) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (c + u < c1) {
+                const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)(c + u) * 1024);
+                wl[u] = __builtin_nontemporal_load(ptr);
+                wh[u] = __builtin_nontemporal_load(ptr + 64);
+            } else {
+                wl[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                wh[u] = wl[u];
+            }
+        }
+    };
+    auto compute = [&](const h8 (&wl)[CH], const h8 (&wh)[CH], int buf) {
+        const char *base = smem + buf * STAGE;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = 16 * i + li;
+                const h8 a0 = *reinterpret_cast<const h8 *>(base + u * MP * 128 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
+                const h8 a1 = *reinterpret_cast<const h8 *>(base + u * MP * 128 + r * 128 + (((4 + g) ^ ((r >> 1) & 7)) << 4));
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], a0, acc[i], 0, 0, 0);   // C^T tile
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], a1, acc[i], 0, 0, 0);
+            }
+    };
+    w_load(wlA, whA, c0);
+    a_load(c0);
+    int buf = 0;
+    for (int c = c0; c < c1; c += 2 * CH) {
+        a_store(buf, c);
+        __syncthreads();
+        if (c + CH < c1) { a_load(c + CH); w_load(wlB, whB, c + CH); }
+        compute(wlA, whA, buf);
+        buf ^= 1;
+        if (c + CH < c1) {
+            a_store(buf, c + CH);
+            __syncthreads();
+            if (c + 2 * CH < c1) { a_load(c + 2 * CH); w_load(wlA, whA, c + 2 * CH); }
+            compute(wlB, whB, buf);
+            buf ^= 1;
+        }
+    }
+
+    // ---- row statistics ----
+    if (NORM) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            float s = ssq[j];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            if ((tid & 15) == 0) rss[(tid >> 4) + 16 * j] = s;
+        }
+        __syncthreads();
+    }
+
+    if (ksplit > 1) {
+        float *slab = p.ws + (int64_t)ks * p.M * p.N;
+        if (panel_ok) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = 16 * i + li;
+                const int nb = panel * 16 + 4 * g;
+                if (m < p.M) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) slab[(int64_t)m * p.N + nb + r] = acc[i][r];
+                }
+            }
+        }
+        if (NORM && blockIdx.x == 0 && tid < p.M) (p.ws + (int64_t)ksplit * p.M * p.N)[ks * p.M + tid] = rss[tid];
+        return;
+    }
+
+    // ---- in-kernel epilogue ----
+    float rstd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rstd[i] = NORM ? rsqrtf(rss[16 * i + li] / (float)p.K + p.norm_eps) : 1.0f;
+    if (EPI == EPI_SILU_GU16) {
+        // panels alternate gate / up: odd waves hand their tile to the even wave on their left
+        __syncthreads();
+        if (wave & 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[(((wave >> 1) * MT + i) * 4 + r) * 64 + lane] = acc[i][r] * rstd[i];
+        }
+        __syncthreads();
+        if ((wave & 1) == 0 && panel_ok) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = 16 * i + li;
+                if (m >= p.M) continue;
+                f4 up;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) up[r] = xch[(((wave >> 1) * MT + i) * 4 + r) * 64 + lane];
+                store4<EPI>(p, m, panel * 16 + 4 * g, acc[i] * rstd[i], up);
+            }
+        }
+    } else if (panel_ok) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = 16 * i + li;
+            if (m < p.M) store4<EPI>(p, m, panel * 16 + 4 * g, acc[i] * rstd[i], acc[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // big: 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 each = 8 x 4 MFMA tiles, 128 accumulator
 // registers), K streamed in 32-deep stages through a 4-slot LDS ring (4 x 32 KB = 128 KB) filled by
 // LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  Three stages are kept in
@@ -651,6 +854,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
     if (i >= (int64_t)p.M * nout) return;
     const int m = (int)(i / nout), no = (int)(i % nout);
     const int64_t slab = (int64_t)p.M * p.N;
+    float rstd = 1.0f;
+    if (p.Af) {   // fused RMSNorm: the k-parts left their partial sum(h^2) behind the slabs
+        float q = 0.f;
+        for (int k = 0; k < ksplit; ++k) q += p.ws[ksplit * slab + (int64_t)k * p.M + m];
+        rstd = rsqrtf(q / (float)p.K + p.norm_eps);
+    }
     float v;
     if (EPI == EPI_SILU_GU16) {
         const int n = (no >> 4) * 32 + (no & 15);
@@ -659,17 +868,62 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
             gate += p.ws[k * slab + (int64_t)m * p.N + n];
             up += p.ws[k * slab + (int64_t)m * p.N + n + 16];
         }
+        gate *= rstd;
+        up *= rstd;
         if (p.bias) { gate += p.bias[n]; up += p.bias[n + 16]; }
         v = silu(gate) * up;
     } else {
         v = 0.f;
         for (int k = 0; k < ksplit; ++k) v += p.ws[k * slab + (int64_t)m * p.N + no];
+        v *= rstd;
         if (p.bias) v += p.bias[no];
         if (EPI == EPI_GELU) v = gelu_erf(v);
     }
     if (p.residual) v += p.residual[(int64_t)m * p.ldr + no];
     if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
     else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
+}
+
+template <int MT, int EPI, bool NORM>
+static hipError_t launch_mid_t(const GemmParams &p, hipStream_t s) {
+    const int blocks = cdiv((p.N + 15) >> 4, 4), chunks = p.K / 64;
+    // k-parts: enough workgroups for ~8 waves per CU, at least 4 chunks each, slabs within the workspace
+    int ks = 1;
+    if (p.ws && blocks < 384) {
+        ks = cdiv(512, blocks);
+        ks = ks > 8 ? 8 : ks;
+        if (ks > chunks / 4) ks = chunks / 4;
+        while (ks > 1 && ((int64_t)ks * p.M * p.N + (int64_t)ks * p.M) * 4 > p.ws_bytes) --ks;
+        if (ks < 1) ks = 1;
+    }
+    constexpr int CH = MT <= 2 ? 4 : 1;
+    const size_t lds = 2 * CH * 16 * MT * 128 + 16 * MT * sizeof(float) + 2 * MT * 4 * 64 * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_mid_kernel<MT, EPI, NORM>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_mid_kernel<MT, EPI, NORM>), dim3(blocks, ks), dim3(256), lds, s, p, ks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, p, ks);
+    return hipGetLastError();
+}
+
+template <int EPI, bool NORM>
+static hipError_t launch_mid_e(const GemmParams &p, hipStream_t s) {
+    switch (cdiv(p.M, 32)) {
+        case 1: return launch_mid_t<2, EPI, NORM>(p, s);
+        case 2: return launch_mid_t<4, EPI, NORM>(p, s);
+        case 3: return launch_mid_t<6, EPI, NORM>(p, s);
+        case 4: return launch_mid_t<8, EPI, NORM>(p, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int EPI>
@@ -720,8 +974,11 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 63) || (p.lda & 7)) return hipErrorInvalidValue;
     if (p.epi == EPI_SILU_GU16 && (p.N & 31)) return hipErrorInvalidValue;
     const bool skinny = p.M <= SKINNY_MAX_M;
+    static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;   // A/B aid
+    const bool mid = !skinny && p.M <= MID_MAX_M && !no_mid;
     if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;
-    if (p.Af && !skinny) return hipErrorInvalidValue;   // fused norm exists in the skinny kernel only
+    if (p.Af && !skinny && !mid) return hipErrorInvalidValue;   // fused norm: skinny and mid kernels only
+    if (p.Af && p.epi == EPI_GELU) return hipErrorInvalidValue;
     if (skinny) {
         if (p.Af) {
             switch (p.epi) {
@@ -734,6 +991,19 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
             case EPI_NONE: return launch_skinny_e<EPI_NONE, false>(p, s);
             case EPI_GELU: return launch_skinny_e<EPI_GELU, false>(p, s);
             case EPI_SILU_GU16: return launch_skinny_e<EPI_SILU_GU16, false>(p, s);
+        }
+    } else if (mid) {
+        if (p.Af) {
+            switch (p.epi) {
+                case EPI_NONE: return launch_mid_e<EPI_NONE, true>(p, s);
+                case EPI_SILU_GU16: return launch_mid_e<EPI_SILU_GU16, true>(p, s);
+            }
+            return hipErrorInvalidValue;
+        }
+        switch (p.epi) {
+            case EPI_NONE: return launch_mid_e<EPI_NONE, false>(p, s);
+            case EPI_GELU: return launch_mid_e<EPI_GELU, false>(p, s);
+            case EPI_SILU_GU16: return launch_mid_e<EPI_SILU_GU16, false>(p, s);
         }
     } else {
         switch (p.epi) {

@@ -77,6 +77,7 @@ def test_synthetic_fill_matches_numpy_twin(dev):
 @pytest.mark.parametrize("M,N,K,epi,f32out,resid", [
     (1, 64, 64, 0, 0, False), (1, 4096, 4096, 0, 1, True), (3, 160, 320, 1, 0, False), (8, 256, 1280, 0, 0, False),
     (16, 512, 128, 2, 0, False), (17, 96, 192, 0, 1, True), (33, 64, 256, 1, 0, False), (64, 1024, 512, 2, 0, False),
+    (48, 4096, 4096, 0, 1, True), (96, 6144, 4096, 0, 0, False), (128, 1056, 1280, 1, 0, False), (70, 4096, 14336, 0, 1, True),
     (65, 128, 64, 0, 0, False), (130, 384, 320, 1, 0, False), (257, 200, 128, 0, 1, True), (300, 512, 1280, 2, 0, False),
     (514, 3840, 1280, 0, 0, False), (1, 32768, 5120, 1, 0, False),
     # >= 192 tiles of 256 x 256: the 8-wave LDS-DMA pipelined kernel (ragged M/N, 2 / 4 / 10 / 20 K stages)
@@ -118,6 +119,35 @@ def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
     torch.cuda.synchronize()
     err = (out.double().cpu() - acc).abs().max().item()
     assert err <= 2e-3 * acc.abs().max().item() + 1e-5, err
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (1, 256, 4096, 0), (5, 512, 1024, 2), (16, 96, 320, 0), (17, 6144, 4096, 0), (40, 640, 1280, 2), (64, 4096, 4096, 0),
+    (64, 28672, 4096, 2), (100, 208, 192, 0), (128, 2048, 512, 2), (96, 4096, 14336, 0),
+])
+def test_gemm_fused_rmsnorm(micro, dev, M, N, K, epi):
+    """C = epi(rmsnorm(X) W'^T) with X the fp32 residual stream: skinny (M <= 16) and mid (M <= 128) kernels,
+    with and without k-parts."""
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model, _ = micro
+    g = torch.Generator().manual_seed(M * 13 + N)
+    X = torch.randn(M, K, generator=g) * 3.0
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    xn = X.double() * torch.rsqrt(X.double().pow(2).mean(-1, keepdim=True) + 1e-5)
+    acc = xn @ W.double().T
+    nout = N
+    if epi == 2:
+        nout = N // 2
+        a = acc.view(M, N // 32, 2, 16)
+        acc = (torch.nn.functional.silu(a[:, :, 0]) * a[:, :, 1]).reshape(M, nout)
+    dX, dW = X.to(dev), tile_weight(W.to(dev))
+    out = torch.empty(M, nout, dtype=torch.float16, device=dev)
+    _cabi.check(_cabi.lib().opus_debug_gemm_norm(model._ctx, dX.data_ptr(), dW.data_ptr(), out.data_ptr(), M, N, K, epi, 0, 1e-5, None))
+    torch.cuda.synchronize()
+    err = (out.double().cpu() - acc).abs().max().item()
+    # the kernel rounds h (not h/rms) to fp16: same relative precision, tolerance scaled by the output range
+    assert err <= 4e-3 * acc.abs().max().item() + 1e-5, err
 
 
 @pytest.mark.parametrize("B,T,heads,group,hd,causal", [
