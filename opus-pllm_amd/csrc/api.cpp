@@ -365,12 +365,22 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     p.A = A; p.Af = Af; p.norm_eps = eps; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.residual = residual; p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
     p.ws = c->gemm_ws; p.ws_bytes = c->gemm_ws_bytes;
+    p.ev0 = p.ev1 = nullptr;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
                          (residual ? 4.0 * M * nout : 0.0);
     int klass = M <= SKINNY_MAX_M ? KC_SKINNY : KC_TILE;
-    Timed t(c, s, klass, bytes);
-    hipError_t e = launch_gemm(p, s, &klass);
+    hipError_t e;
+    if (c->timing && klass == KC_SKINNY) {
+        // the dominant kernel is timed by its own dispatch timestamps (hipExtLaunchKernelGGL start/stop events)
+        (void)hipEventCreate(&p.ev0);
+        (void)hipEventCreate(&p.ev1);
+        e = launch_gemm(p, s, &klass);
+        c->recs.push_back(TimeRec{klass, p.ev0, p.ev1, bytes});
+    } else {
+        Timed t(c, s, klass, bytes);
+        e = launch_gemm(p, s, &klass);
+    }
     if (e != hipSuccess) return fail(OPUS_EHIP, "gemm M=%d N=%d K=%d failed: %s", M, N, K, hipGetErrorString(e));
     return OPUS_OK;
 }
@@ -742,7 +752,7 @@ extern "C" int opus_debug_gemm(opus_ctx *c, const void *A, const void *W, const 
 extern "C" int opus_debug_gemm_norm(opus_ctx *c, const float *A, const void *W, void *Cp, int32_t M, int32_t N, int32_t K,
                                     int32_t epi, int32_t out_f32, float eps, void *stream) {
     if (!c || !A || !W || !Cp) return fail(OPUS_EBADARG, "debug_gemm_norm: null pointer");
-    if (M < 1 || M > MID_MAX_M || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_norm: M <= 128, K %% 64 == 0");
+    if (M < 1 || M > MID_MAX_M || N < 1 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_norm: M <= 64, K %% 64 == 0");
     if (epi != 0 && epi != 2) return fail(OPUS_EBADARG, "debug_gemm_norm: epilogue 0 or 2");
     HIPC(hipSetDevice(c->device));
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;

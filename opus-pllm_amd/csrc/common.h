@@ -16,7 +16,7 @@ enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
 // above it the LDS-tiled MFMA kernel (with split-K when the output has few tiles) streams the weights.
 constexpr int SKINNY_MAX_M = 16;
 // M up to which the mid kernel (LDS-shared activations, per-wave weight stream, fused RMSNorm) is used
-constexpr int MID_MAX_M = 128;
+constexpr int MID_MAX_M = 64;   // (65..128 rows measured faster on the split-K tile kernel)
 enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_COUNT = 5 };
 
 // C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.
@@ -37,6 +37,9 @@ struct GemmParams {
     int epi;
     float *ws;              // split-K workspace (fp32 partial slabs) or nullptr
     int64_t ws_bytes;
+    // measurement: when set, the skinny kernel is dispatched with hipExtLaunchKernelGGL so that these events
+    // carry the dispatch's own start / end timestamps (what rocprofv3 reports), not a bracket around it
+    hipEvent_t ev0, ev1;
 };
 
 // Flash-style attention over strided Q/K/V (fp16).  Q(b,h,t,:) = Q + b*q_sb + t*q_st + h*HD etc.;

@@ -17,6 +17,7 @@
 //  * gemm_tile (M > 64): 128x128x64 LDS-tiled MFMA kernel (4 waves x 64x64), register-staged double
 //    buffering; A image XOR-swizzled, B image kept in fragment order (linear ds_read_b128).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 namespace opus {
@@ -489,7 +490,8 @@ static hipError_t launch_skinny_t(const GemmParams &p, hipStream_t s) {
             set = lds;
         }
     }
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, NORM, ALDS>), dim3(groups), dim3(64 * W), lds, s, p);
+    if (p.ev0) hipExtLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, NORM, ALDS>), dim3(groups), dim3(64 * W), lds, s, p.ev0, p.ev1, 0, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, NORM, ALDS>), dim3(groups), dim3(64 * W), lds, s, p);
     return hipGetLastError();
 }
 

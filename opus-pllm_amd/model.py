@@ -262,19 +262,26 @@ class OpusLlamaForCausalLM:
         self._leave()
         return out[:, : n_out.value].long()
 
-    def generate_from_tokens(self, d_tokens: torch.Tensor, d_lens: torch.Tensor, input_ids: torch.Tensor,
+    def generate_from_tokens(self, d_tokens, d_lens, input_ids: torch.Tensor,
                              attention_mask: Optional[torch.Tensor], max_new_tokens: int, eos: Sequence[int] = (),
-                             pad_token_id: int = 0) -> torch.Tensor:
+                             pad_token_id: int = 0, bucket_rows: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
         """generate() for callers whose inputs are already resident in HBM: ESM-2 token ids int32
         [B,T] + lens int32 [B] (alphabet.batch_convert), prompt ids int64 [B,T_text] on the device.
-        Same result as generate(input_ids, seqs, ...); used by bench.py for the timed region."""
+        Same result as generate(input_ids, seqs, ...); used by bench.py for the timed region.
+        Length-bucketed form: d_tokens / d_lens / bucket_rows are lists (one entry per bucket; bucket_rows[k] =
+        int64 device tensor with the batch rows of bucket k), as encode_seq2embedding buckets strings."""
         cfg = self.cfg
-        B, T = d_tokens.shape
+        buckets = list(zip(d_tokens, d_lens, bucket_rows)) if bucket_rows is not None else [(d_tokens, d_lens, None)]
+        B = input_ids.shape[0]
         s = self._enter()
         with torch.cuda.stream(self._stream):
             pooled = torch.empty((B, cfg.enc_dim), dtype=torch.float32, device=self.device)
-            _cabi.check(self._lib.opus_esm2_encode(self._ctx, d_tokens.data_ptr(), d_lens.data_ptr(), B, T,
-                                                   pooled.data_ptr(), s))
+            for tok, lens, rows in buckets:
+                out = pooled if rows is None else torch.empty((tok.shape[0], cfg.enc_dim), dtype=torch.float32, device=self.device)
+                _cabi.check(self._lib.opus_esm2_encode(self._ctx, tok.data_ptr(), lens.data_ptr(), tok.shape[0], tok.shape[1],
+                                                       out.data_ptr(), s))
+                if rows is not None:
+                    pooled[rows] = out
             prot = torch.empty((B, cfg.n_prot_tokens, cfg.dec_dim), dtype=torch.float16, device=self.device)
             _cabi.check(self._lib.opus_projector_forward(self._ctx, pooled.data_ptr(), B, prot.data_ptr(), None, s))
         self._leave()
