@@ -142,13 +142,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # one rank per GPU; OPUS_BENCH_BACKEND=gloo (+ ranks sharing a GPU) exists only to rehearse the N > 1 code
+    # path on a one-GPU box - the driver's multi-GPU runs use nccl (= RCCL over xGMI)
+    backend = os.environ.get("OPUS_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collectives run
 
     from opus_pllm_amd.model import OpusLlamaForCausalLM
     from opus_pllm_amd.weights import DeviceWeights
@@ -181,12 +189,12 @@ def main():
         d_len = torch.from_numpy(lens).to(dev)
     ids = torch.tensor([synth.synth_prompt_ids(cfg.dec_vocab, rank * B + i, n_text=n_text) for i in range(B)], device=dev)
     mask = torch.ones_like(ids, dtype=torch.bool)
-    gathered = [torch.empty((B, N_new), dtype=torch.long, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty((B, N_new), dtype=torch.long, device=cdev) for _ in range(world)] if world > 1 else None
 
     def step():
         out = model.generate_from_tokens(d_tok, d_len, ids, mask, N_new, (), 0, bucket_rows)
         if world > 1:
-            dist.all_gather(gathered, out.contiguous())       # RCCL over xGMI: [B, N_new] ids per rank
+            dist.all_gather(gathered, out.contiguous().to(cdev))   # RCCL over xGMI: [B, N_new] ids per rank
         return out
 
     def fence():
@@ -206,7 +214,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.shape == (B, N_new)
