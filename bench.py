@@ -60,6 +60,8 @@ def parse():
     p.add_argument("--mixed-lengths", action="store_true", help="C3: lengths uniform in [128,1024], seed 7")
     p.add_argument("--new-tokens", type=int, default=32)
     p.add_argument("--model", default="llama3_8b", choices=list(opa.PRESETS))
+    p.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling head (reference default 0.1); 0 = greedy (BASELINE)")
+    p.add_argument("--top-p", type=float, default=0.7)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     return p.parse_args()
@@ -192,7 +194,8 @@ def main():
     gathered = [torch.empty((B, N_new), dtype=torch.long, device=cdev) for _ in range(world)] if world > 1 else None
 
     def step():
-        out = model.generate_from_tokens(d_tok, d_len, ids, mask, N_new, (), 0, bucket_rows)
+        out = model.generate_from_tokens(d_tok, d_len, ids, mask, N_new, (), 0, bucket_rows,
+                                         sampler=(a.temperature, a.top_p, 1234) if a.temperature > 0 else None)
         if world > 1:
             dist.all_gather(gathered, out.contiguous().to(cdev))   # RCCL over xGMI: [B, N_new] ids per rank
         return out

@@ -143,6 +143,17 @@ int opus_generate_greedy(opus_ctx *ctx, const void *d_embeds, const uint8_t *d_m
                          int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id,
                          int32_t *d_out_ids, int32_t *n_out, void *stream);
 
+/* Row N1 (sampling head, the reference's default decode mode: run_opus_ddp.py:126-128,156-157 temperature 0.1,
+ * top_p 0.7): same loop with next = multinomial(softmax(top_p_filter(logits / temperature))) per transformers'
+ * TemperatureLogitsWarper + TopPLogitsWarper; draws come from a counter-based generator keyed by
+ * (seed, row, step), so a given seed reproduces its tokens.  Parity with the reference is distributional. */
+int opus_generate_sample(opus_ctx *ctx, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
+                         int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id, float temperature,
+                         float top_p, uint64_t seed, int32_t *d_out_ids, int32_t *n_out, void *stream);
+/* Diagnostic: one draw per row of fp32 logits [B, dec_vocab] (synchronises the stream). */
+int opus_debug_sample(opus_ctx *ctx, const float *d_logits, int32_t B, float temperature, float top_p, uint64_t seed,
+                      int32_t step, int32_t *d_tokens, void *stream);
+
 /* Diagnostic entry points (kernel-level parity tests and micro-benchmarks; not part of the path's
  * drop-in surface).  opus_debug_gemm: C[M,Nout] = epi(A[M,K] W[N,K]^T + bias) (+ residual fp32);
  * epi 0 none, 1 erf-GELU, 2 silu(gate)*up with W rows in [16 gate | 16 up] groups (Nout = N/2).

@@ -72,6 +72,9 @@ SIGNATURES = {
     "opus_debug_gemm_norm": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
     "opus_debug_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_float, _P]),
+    "opus_generate_sample": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                       C.c_float, C.c_float, C.c_uint64, _P, C.POINTER(C.c_int32), _P]),
+    "opus_debug_sample": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_int32, _P, _P]),
     "opus_timing_enable": (C.c_int, [_P, C.c_int32]),
     "opus_timing_reset": (C.c_int, [_P]),
     "opus_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),

@@ -74,7 +74,11 @@ struct opus_ctx {
     float *e_x, *e_hid, *p_pool_dummy;
     half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
     half_t *p_xn, *p_y, *p_z[2];
-    float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws;
+    float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws, *d_probs;
+    uint64_t *d_seed;
+    int32_t *d_chosen;
+    // sampling head (0 = greedy)
+    float samp_temp = 0.f, samp_top_p = 1.f;
     int64_t gemm_ws_bytes = 0;
     half_t *d_xn, *d_qkv, *d_ctx, *d_act, *d_xln, *kc, *vc;
     float *cs_enc, *cs_dec;
@@ -87,6 +91,7 @@ struct opus_ctx {
     hipGraphExec_t gexec = nullptr;
     int g_B = -1, g_T = -1, g_maxnew = -1, g_pad = 0, g_neos = -1;
     const int32_t *g_out = nullptr;
+    float g_temp = 0.f, g_top_p = 1.f;
     // timing
     bool timing = false;
     std::vector<TimeRec> recs;
@@ -150,6 +155,9 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_eos = k.take<int32_t>(64);
     c->d_plan = k.take<int32_t>(4 * B + 8);
     c->d_pval = k.take<float>(64 * B);
+    c->d_probs = k.take<float>(B * (size_t)g.dec_vocab);
+    c->d_seed = k.take<uint64_t>(2);
+    c->d_chosen = k.take<int32_t>(B);
     c->gemm_ws_bytes = 64ll << 20;   // split-K slabs of the tile GEMM
     c->gemm_ws = k.take<float>((size_t)c->gemm_ws_bytes / sizeof(float));
     c->d_pidx = k.take<int32_t>(64 * B);
@@ -652,11 +660,20 @@ extern "C" int opus_llama_decode_step(opus_ctx *c, const int32_t *d_tok, float *
     return OPUS_OK;
 }
 
+// next token per row: argmax (greedy) or temperature / top-p sampling, then the GenerationMixin bookkeeping
 static int argmax(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id, int32_t *d_out) {
     const opus_config &g = c->cfg;
-    KL(KC_OTHER, 4.0 * c->cur_B * g.dec_vocab, launch_argmax_partial(c->d_logits, c->cur_B, g.dec_vocab, c->d_pval, c->d_pidx, s));
+    const int32_t *chosen = nullptr;
+    if (c->samp_temp > 0.f) {
+        KL(KC_OTHER, 4.0 * 42 * c->cur_B * g.dec_vocab,
+           launch_sample_select(c->d_logits, c->cur_B, g.dec_vocab, c->samp_temp, c->samp_top_p, c->d_seed, c->d_step,
+                                c->d_probs, c->d_chosen, s));
+        chosen = c->d_chosen;
+    } else {
+        KL(KC_OTHER, 4.0 * c->cur_B * g.dec_vocab, launch_argmax_partial(c->d_logits, c->cur_B, g.dec_vocab, c->d_pval, c->d_pidx, s));
+    }
     KL(KC_OTHER, 512.0 * c->cur_B,
-       launch_argmax_step(c->d_pval, c->d_pidx, c->cur_B, c->d_eos, n_eos, pad_id, c->d_fin, d_out, max_new, c->d_step,
+       launch_argmax_step(c->d_pval, c->d_pidx, chosen, c->cur_B, c->d_eos, n_eos, pad_id, c->d_fin, d_out, max_new, c->d_step,
                           c->d_next, c->d_nunf, s));
     return OPUS_OK;
 }
@@ -668,10 +685,13 @@ static int greedy_body(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int p
     return decode_step(c, s, c->d_next);
 }
 
-extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
-                                    int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id,
-                                    int32_t *d_out_ids, int32_t *n_out, void *stream) {
+static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T, int32_t max_new,
+                         const int32_t *eos_ids, int32_t n_eos, int32_t pad_id, float temperature, float top_p, uint64_t seed,
+                         int32_t *d_out_ids, int32_t *n_out, void *stream) {
     OPC(need_ready(c));
+    if (temperature < 0.f || top_p <= 0.f || top_p > 1.f) return fail(OPUS_EBADARG, "generate: temperature >= 0 and 0 < top_p <= 1");
+    c->samp_temp = temperature;
+    c->samp_top_p = top_p;
     OPC(check_prefill_args(c, d_embeds, d_mask, B, T));
     if (!d_out_ids || !n_out) return fail(OPUS_EBADARG, "generate_greedy: null pointer");
     if (max_new < 1 || max_new > c->cfg.max_new_tokens)
@@ -680,6 +700,7 @@ extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uin
     hipStream_t s = (hipStream_t)stream;
     const opus_config &g = c->cfg;
     if (n_eos) HIPC(hipMemcpyAsync(c->d_eos, eos_ids, n_eos * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(c->d_seed, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
     HIPC(hipMemsetAsync(c->d_fin, 0, B * sizeof(int32_t), s));
     HIPC(hipMemsetAsync(c->d_nunf, 0, (size_t)max_new * sizeof(int32_t), s));
     OPC(prefill(c, s, (const half_t *)d_embeds, d_mask, B, T));
@@ -688,7 +709,7 @@ extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uin
     const bool use_graph = s != nullptr && !c->timing && !getenv("OPUS_NO_GRAPH");
     auto graph_matches = [&]() {
         return c->gexec && c->g_B == B && c->g_T == T && c->g_maxnew == max_new && c->g_pad == pad_id &&
-               c->g_neos == n_eos && c->g_out == d_out_ids;
+               c->g_neos == n_eos && c->g_out == d_out_ids && c->g_temp == temperature && c->g_top_p == top_p;
     };
     const bool same_graph = graph_matches();
     std::vector<int32_t> nunf(max_new, 1);
@@ -714,6 +735,7 @@ extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uin
                 (void)hipGraphDestroy(graph);
                 if (ee != hipSuccess) { c->gexec = nullptr; return fail(OPUS_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ee)); }
                 c->g_B = B; c->g_T = T; c->g_maxnew = max_new; c->g_pad = pad_id; c->g_neos = n_eos;
+                c->g_temp = temperature; c->g_top_p = top_p;
                 c->g_out = d_out_ids;
             }
             HIPC(hipGraphLaunch(c->gexec, s));
@@ -734,6 +756,34 @@ extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uin
     int n = produced;
     for (int k = 0; k < produced; ++k) if (nunf[k] == 0) { n = k + 1; break; }
     *n_out = n;
+    return OPUS_OK;
+}
+
+extern "C" int opus_generate_greedy(opus_ctx *c, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
+                                    int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id,
+                                    int32_t *d_out_ids, int32_t *n_out, void *stream) {
+    return generate_impl(c, d_embeds, d_mask, B, T, max_new, eos_ids, n_eos, pad_id, 0.f, 1.f, 0, d_out_ids, n_out, stream);
+}
+
+extern "C" int opus_generate_sample(opus_ctx *c, const void *d_embeds, const uint8_t *d_mask, int32_t B, int32_t T,
+                                    int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id, float temperature,
+                                    float top_p, uint64_t seed, int32_t *d_out_ids, int32_t *n_out, void *stream) {
+    if (!(temperature > 0.f)) return fail(OPUS_EBADARG, "generate_sample: temperature must be > 0 (use opus_generate_greedy)");
+    return generate_impl(c, d_embeds, d_mask, B, T, max_new, eos_ids, n_eos, pad_id, temperature, top_p, seed, d_out_ids, n_out,
+                         stream);
+}
+
+/* Diagnostic: one draw per row from fp32 logits [B,V] with the sampling head (step counter = `step`). */
+extern "C" int opus_debug_sample(opus_ctx *c, const float *d_logits, int32_t B, float temperature, float top_p, uint64_t seed,
+                                 int32_t step, int32_t *d_tokens, void *stream) {
+    if (!c || !d_logits || !d_tokens) return fail(OPUS_EBADARG, "debug_sample: null pointer");
+    if (B < 1 || B > c->cfg.max_batch || !(temperature > 0.f) || top_p <= 0.f || top_p > 1.f) return fail(OPUS_EBADARG, "debug_sample: argument");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPC(hipMemcpyAsync(c->d_seed, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(c->d_plan, &step, sizeof(step), hipMemcpyHostToDevice, s));
+    HIPC(launch_sample_select(d_logits, B, c->cfg.dec_vocab, temperature, top_p, c->d_seed, c->d_plan, c->d_probs, d_tokens, s));
+    HIPC(hipStreamSynchronize(s));   // seed / step are host temporaries
     return OPUS_OK;
 }
 

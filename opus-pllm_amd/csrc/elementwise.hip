@@ -418,6 +418,7 @@ hipError_t launch_argmax_partial(const float *logits, int B, int V, float *pval,
 // Stage 2: one wave per row combines the partials (lowest index wins ties, as torch.argmax), then the
 // GenerationMixin bookkeeping: finished rows emit pad_id; a row finishes when it emits an EOS id.
 __global__ __launch_bounds__(64) void argmax_step_kernel(const float *__restrict__ pval, const int32_t *__restrict__ pidx,
+                                                         const int32_t *__restrict__ chosen,
                                                          const int32_t *__restrict__ eos, int n_eos, int pad_id,
                                                          int32_t *__restrict__ finished, int32_t *__restrict__ out_ids,
                                                          int max_new, const int32_t *__restrict__ step,
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(const float *__restrict
         const int i = __shfl_xor(bi, o, 64);
         if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
     }
+    if (chosen) bi = chosen[b];               // sampling: the token was drawn by sample_select_kernel
     if (lane == 0) {
         const int st = *step;
         int fin = finished[b];
@@ -443,11 +445,107 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(const float *__restrict
         if (!fin && st < max_new) atomicAdd(&n_unf[st], 1);
     }
 }
-hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, int B, const int32_t *eos, int n_eos, int pad_id,
-                              int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step, int32_t *next_tok,
-                              int32_t *n_unfinished, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, eos, n_eos, pad_id, finished, out_ids,
+hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, const int32_t *chosen, int B, const int32_t *eos,
+                              int n_eos, int pad_id, int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
+                              int32_t *next_tok, int32_t *n_unfinished, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, chosen, eos, n_eos, pad_id, finished, out_ids,
                        max_new, step, next_tok, n_unfinished);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ sampling head (N1)
+// HF sampling as the reference drives it (run_opus_ddp.py:126-128: temperature, top_p; transformers
+// TemperatureLogitsWarper -> TopPLogitsWarper -> softmax -> multinomial), one workgroup per row:
+//   p_i = exp(l_i / T - max);  keep token i iff  sum_{p_j <= p_i} p_j  >  (1 - top_p) * Z   (the ascending
+//   cumulative sum of TopPLogitsWarper; tokens of exactly equal probability are kept or dropped together);
+//   draw u from a counter-based generator (seed, row, step) and invert the CDF of the kept set in index order.
+// The nucleus threshold is found by bisection on the probability value (40 halvings: narrower than fp32
+// spacing), every pass a fixed-order block reduction, so a (seed, row, step) triple always gives the same token.
+__device__ __forceinline__ float block_sum256(float v, float *scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+__device__ __forceinline__ float block_max256(float v, float *scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+}
+
+__global__ __launch_bounds__(256) void sample_select_kernel(const float *__restrict__ logits, int V, float inv_temp,
+                                                            float top_p, const uint64_t *__restrict__ seed_p, const int32_t *__restrict__ step,
+                                                            float *__restrict__ probs, int32_t *__restrict__ chosen) {
+    __shared__ float scratch[4];
+    __shared__ float s_pref[257];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *row = logits + (int64_t)b * V;
+    float *pr = probs + (int64_t)b * V;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i] * inv_temp);
+    mx = block_max256(mx, scratch);
+    float z = 0.f;
+    for (int i = tid; i < V; i += 256) {
+        const float p = __expf(row[i] * inv_temp - mx);
+        pr[i] = p;
+        z += p;
+    }
+    const float Z = block_sum256(z, scratch);
+    const float cut = (1.0f - top_p) * Z;
+    // bisection: invariant  S_le(lo) <= cut < S_le(hi)  with S_le(x) = sum of p_i <= x; S_le(1) = Z > cut
+    float lo = 0.f, hi = 1.0f;
+    for (int it = 0; it < 40; ++it) {
+        const float mid = 0.5f * (lo + hi);
+        float s = 0.f;
+        for (int i = tid; i < V; i += 256) {
+            const float p = pr[i];
+            s += p <= mid ? p : 0.f;
+        }
+        s = block_sum256(s, scratch);
+        if (s > cut) hi = mid; else lo = mid;
+    }
+    // kept set = { p_i > lo }; contiguous index chunks per thread, CDF inversion in index order
+    const int per = (V + 255) / 256;
+    const int i0 = tid * per, i1 = (i0 + per < V ? i0 + per : V);
+    float mine = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float p = pr[i];
+        mine += p > lo ? p : 0.f;
+    }
+    s_pref[tid + 1] = mine;
+    if (tid == 0) s_pref[0] = 0.f;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= 256; ++t) s_pref[t] += s_pref[t - 1];     // fixed order
+    __syncthreads();
+    const float total = s_pref[256];
+    uint64_t h = splitmix64(*seed_p ^ (0x9E3779B97F4A7C15ull * (uint64_t)(b + 1)) ^ ((uint64_t)(*step + 1) << 32));
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);               // [0, 1)
+    const float target = u * total;
+    if (s_pref[tid] <= target && target < s_pref[tid + 1]) {
+        float run = s_pref[tid];
+        int pick = -1, last_kept = -1;
+        for (int i = i0; i < i1; ++i) {
+            const float p = pr[i];
+            if (p > lo) {
+                last_kept = i;
+                run += p;
+                if (target < run) { pick = i; break; }
+            }
+        }
+        chosen[b] = pick >= 0 ? pick : last_kept;
+    }
+    if (tid == 0 && !(target < total)) chosen[b] = 0;                       // total == 0 cannot happen (max p = 1)
+}
+hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, const uint64_t *seed,
+                                const int32_t *step, float *probs, int32_t *chosen, hipStream_t s) {
+    hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(256), 0, s, logits, V, 1.0f / temperature, top_p, seed, step,
+                       probs, chosen);
     return hipGetLastError();
 }
 

@@ -7,7 +7,7 @@
 
 Flow (run_opus_ddp.py:47-148): load -> read JSON -> contiguous split over ranks -> batches of 8 -> prompt ->
 tokenizer_seq_token -> left-pad -> generate -> decode, cut at '###' -> gather in rank order -> rank 0 saves.
-Differences, all deliberate: greedy decode is the default (sampling is row N1), the gather moves token ids
+Differences, all deliberate: the gather moves token ids
 (int tensor all-gather over RCCL) instead of pickled strings, task metrics (metrics_computing_opi.py) are not run.
 """
 from __future__ import annotations
@@ -82,7 +82,7 @@ if __name__ == "__main__":
     p.add_argument("--opus-pllm-weights-path", type=str, default="synthetic")
     p.add_argument("--input_path", type=str, required=True)
     p.add_argument("--save_path", type=str, required=True)
-    p.add_argument("--temperature", type=float, default=0.0)
+    p.add_argument("--temperature", type=float, default=0.1)        # reference default: sampling (run_opus_ddp.py:156)
     p.add_argument("--top_p", type=float, default=0.7)
     p.add_argument("--num_beams", type=int, default=1)
     p.add_argument("--max_new_tokens", type=int, default=None)

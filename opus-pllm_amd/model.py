@@ -223,15 +223,22 @@ class OpusLlamaForCausalLM:
             raise NotImplementedError("`inputs_embeds` is not supported")
         do_sample = bool(kwargs.pop("do_sample", False))
         temperature = kwargs.pop("temperature", None)
-        kwargs.pop("top_p", None)
+        top_p = kwargs.pop("top_p", None)
+        seed = kwargs.pop("seed", None)
         num_beams = int(kwargs.pop("num_beams", 1) or 1)
         max_new = int(kwargs.pop("max_new_tokens", 32))
         kwargs.pop("use_cache", None)
         pad_id = kwargs.pop("pad_token_id", self.generation_config.pad_token_id)
         eos = kwargs.pop("eos_token_id", self.generation_config.eos_token_id)
         eos = [] if eos is None else ([int(eos)] if isinstance(eos, int) else [int(e) for e in eos])
-        if do_sample and temperature is not None and float(temperature) > 0:
-            raise NotImplementedError("sampling (temperature/top-p) is row N1 of SURVEY 8f: only greedy decode is built")
+        sampler = None
+        if do_sample:       # HF: temperature defaults to 1.0, top_p to 1.0; draws keyed by (seed, row, step)
+            t = 1.0 if temperature is None else float(temperature)
+            if not t > 0:
+                raise ValueError("`temperature` has to be a strictly positive float when do_sample=True")
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # follows torch.manual_seed
+            sampler = (t, 1.0 if top_p is None else float(top_p), int(seed))
         if num_beams != 1:
             raise NotImplementedError("beam search is not built (greedy only)")
         if pad_id is None:
@@ -246,9 +253,9 @@ class OpusLlamaForCausalLM:
             dummy = torch.zeros((inputs.shape[0], self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16,
                                 device=self.device)
             embeds, mask, _ = self._splice(inputs, attention_mask, dummy, True)
-        return self._greedy(embeds, mask, max_new, eos, int(pad_id))
+        return self._greedy(embeds, mask, max_new, eos, int(pad_id), sampler)
 
-    def _greedy(self, embeds, mask, max_new, eos, pad_id) -> torch.Tensor:
+    def _greedy(self, embeds, mask, max_new, eos, pad_id, sampler=None) -> torch.Tensor:
         B, T, _ = embeds.shape
         embeds = embeds.contiguous()
         mask = mask.to(torch.uint8).contiguous()
@@ -257,14 +264,20 @@ class OpusLlamaForCausalLM:
             out = torch.full((B, max_new), pad_id, dtype=torch.int32, device=self.device)
             n_out = C.c_int32(0)
             eos_arr = (C.c_int32 * max(1, len(eos)))(*eos)
-            _cabi.check(self._lib.opus_generate_greedy(self._ctx, embeds.data_ptr(), mask.data_ptr(), B, T, max_new,
-                                                       eos_arr, len(eos), pad_id, out.data_ptr(), C.byref(n_out), s))
+            if sampler is None:
+                _cabi.check(self._lib.opus_generate_greedy(self._ctx, embeds.data_ptr(), mask.data_ptr(), B, T, max_new,
+                                                           eos_arr, len(eos), pad_id, out.data_ptr(), C.byref(n_out), s))
+            else:
+                _cabi.check(self._lib.opus_generate_sample(self._ctx, embeds.data_ptr(), mask.data_ptr(), B, T, max_new,
+                                                           eos_arr, len(eos), pad_id, sampler[0], sampler[1], sampler[2],
+                                                           out.data_ptr(), C.byref(n_out), s))
         self._leave()
         return out[:, : n_out.value].long()
 
     def generate_from_tokens(self, d_tokens, d_lens, input_ids: torch.Tensor,
                              attention_mask: Optional[torch.Tensor], max_new_tokens: int, eos: Sequence[int] = (),
-                             pad_token_id: int = 0, bucket_rows: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+                             pad_token_id: int = 0, bucket_rows: Optional[Sequence[torch.Tensor]] = None,
+                             sampler=None) -> torch.Tensor:
         """generate() for callers whose inputs are already resident in HBM: ESM-2 token ids int32
         [B,T] + lens int32 [B] (alphabet.batch_convert), prompt ids int64 [B,T_text] on the device.
         Same result as generate(input_ids, seqs, ...); used by bench.py for the timed region.
@@ -286,7 +299,7 @@ class OpusLlamaForCausalLM:
             _cabi.check(self._lib.opus_projector_forward(self._ctx, pooled.data_ptr(), B, prot.data_ptr(), None, s))
         self._leave()
         emb, mask, _ = self._splice(input_ids, attention_mask, prot, True)
-        return self._greedy(emb, mask, int(max_new_tokens), [int(e) for e in eos], int(pad_token_id))
+        return self._greedy(emb, mask, int(max_new_tokens), [int(e) for e in eos], int(pad_token_id), sampler)
 
     # ------------------------------------------------------------------ parity taps (tests / bench)
     def prefill_logits(self, embeds: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

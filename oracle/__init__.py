@@ -22,3 +22,4 @@ from .splice import tokenizer_seq_token, left_pad_sequence, splice_and_pad  # no
 from .llama import llama_forward, greedy_decode, KVCache  # noqa: F401
 from .lora import lora_merge  # noqa: F401
 from .pipeline import OraclePipeline  # noqa: F401
+from .sampling import sampling_distribution  # noqa: F401

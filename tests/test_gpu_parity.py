@@ -343,9 +343,60 @@ def test_generate_api_errors(micro):
     with pytest.raises(NotImplementedError):
         model.encode_seq2embedding([1, 2, 3])
     with pytest.raises(NotImplementedError):
-        model.generate(ids, ["ACD"], do_sample=True, temperature=0.1)
+        model.generate(ids, ["ACD"], num_beams=4)
+    with pytest.raises(ValueError):
+        model.generate(ids, ["ACD"], do_sample=True, temperature=0.0)
     res = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, None)
     assert res[0] is ids and res[4] is None                    # seq None -> inputs unchanged
+
+
+def test_sampling_head_matches_hf_distribution(micro, dev):
+    """Row N1: temperature + top-p + multinomial.  Every draw lies in the oracle's nucleus and the empirical
+    frequencies of 3200 draws match the oracle distribution (total variation < 0.05); draws are a pure
+    function of (seed, row, step)."""
+    import oracle
+    from opus_pllm_amd import _cabi
+    cfg, model, _ = micro
+    lib = _cabi.lib()
+    V, B = cfg.dec_vocab, 8
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(1, V, generator=g) * 2.0
+    logits = base.repeat(B, 1).to(dev)
+    for temperature, top_p in ((0.7, 0.7), (1.0, 0.9), (0.1, 0.7)):
+        ref = oracle.sampling_distribution(base, temperature, top_p)[0]
+        counts = torch.zeros(V)
+        toks = torch.empty(B, dtype=torch.int32, device=dev)
+        for step in range(400):
+            _cabi.check(lib.opus_debug_sample(model._ctx, logits.data_ptr(), B, temperature, top_p, 1234, step, toks.data_ptr(), None))
+            counts += torch.bincount(toks.cpu().long(), minlength=V).float()
+        freq = counts / counts.sum()
+        assert float(freq[ref == 0].sum()) == 0.0, (temperature, top_p)            # nothing outside the nucleus
+        assert float((freq - ref).abs().sum()) / 2 < 0.05, (temperature, top_p, freq.topk(5), ref.topk(5))
+    a = torch.empty(B, dtype=torch.int32, device=dev)
+    b = torch.empty(B, dtype=torch.int32, device=dev)
+    _cabi.check(lib.opus_debug_sample(model._ctx, logits.data_ptr(), B, 0.7, 0.7, 99, 3, a.data_ptr(), None))
+    _cabi.check(lib.opus_debug_sample(model._ctx, logits.data_ptr(), B, 0.7, 0.7, 99, 3, b.data_ptr(), None))
+    assert torch.equal(a, b)
+
+
+def test_generate_with_sampling(micro, gold, gold_dir):
+    cfg, model, W = micro
+    g = gold("generate_micro")
+    seqs = json.load(open(os.path.join(gold_dir, "generate_micro.seqs.json")))
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    kw = dict(attention_mask=mask, pad_token_id=int(g["pad"]), max_new_tokens=10, use_cache=True)
+    a = model.generate(ids, seqs, do_sample=True, temperature=0.7, top_p=0.7, seed=7, **kw)
+    b = model.generate(ids, seqs, do_sample=True, temperature=0.7, top_p=0.7, seed=7, **kw)    # graph replay
+    c = model.generate(ids, seqs, do_sample=True, temperature=0.7, top_p=0.7, seed=8, **kw)
+    assert a.shape == (3, 10) and torch.equal(a, b) and not torch.equal(a, c)
+    # temperature -> 0 collapses the nucleus onto the arg-max: sampling reproduces the greedy ids
+    cold = model.generate(ids, seqs, do_sample=True, temperature=1e-3, top_p=0.7, seed=3, **kw)
+    assert np.array_equal(cold.cpu().numpy(), g["free_ids"][:, :10])
+    torch.manual_seed(11)
+    d = model.generate(ids, seqs, do_sample=True, temperature=0.7, top_p=0.7, **kw)             # seed from torch's RNG
+    torch.manual_seed(11)
+    e = model.generate(ids, seqs, do_sample=True, temperature=0.7, top_p=0.7, **kw)
+    assert torch.equal(d, e)
 
 
 def test_generate_c1_golden(dev, gold):

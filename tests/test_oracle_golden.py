@@ -119,3 +119,13 @@ def test_lora_merge_restated():
     M = oracle.lora_merge(W, A, B, alpha=8.0, r=4)
     ref = (W.double() + 2.0 * (B.double() @ A.double())).half().float()
     assert (M - ref).abs().max() <= 2 ** -10 * ref.abs().max()
+
+
+def test_sampling_distribution_restates_hf_warpers():
+    """N1 oracle vs the local transformers warpers (the same classes GenerationMixin applies)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopPLogitsWarper
+    torch.manual_seed(0)
+    logits = torch.randn(4, 200) * 3
+    for t, p in ((0.1, 0.7), (0.7, 0.7), (1.3, 0.95)):
+        hf = TopPLogitsWarper(p)(None, TemperatureLogitsWarper(t)(None, logits)).softmax(-1)
+        assert torch.allclose(oracle.sampling_distribution(logits, t, p), hf, atol=1e-7)
