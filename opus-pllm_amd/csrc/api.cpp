@@ -74,7 +74,8 @@ struct opus_ctx {
     float *e_x, *e_hid, *p_pool_dummy;
     half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
     half_t *p_xn, *p_y, *p_z[2];
-    float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws, *d_probs;
+    float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws, *d_probs, *d_zpart, *d_spart;
+    int32_t *d_cand_i, *d_cand_n;
     uint64_t *d_seed;
     int32_t *d_chosen;
     // sampling head (0 = greedy)
@@ -155,7 +156,11 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_eos = k.take<int32_t>(64);
     c->d_plan = k.take<int32_t>(4 * B + 8);
     c->d_pval = k.take<float>(64 * B);
-    c->d_probs = k.take<float>(B * (size_t)g.dec_vocab);
+    c->d_probs = k.take<float>(B * ((size_t)g.dec_vocab + 64 * 4));     // candidate probabilities (per-part slots)
+    c->d_cand_i = k.take<int32_t>(B * ((size_t)g.dec_vocab + 64 * 4));
+    c->d_cand_n = k.take<int32_t>(64 * B);
+    c->d_zpart = k.take<float>(64 * B);
+    c->d_spart = k.take<float>(64 * B);
     c->d_seed = k.take<uint64_t>(2);
     c->d_chosen = k.take<int32_t>(B);
     c->gemm_ws_bytes = 64ll << 20;   // split-K slabs of the tile GEMM
@@ -665,9 +670,9 @@ static int argmax(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id
     const opus_config &g = c->cfg;
     const int32_t *chosen = nullptr;
     if (c->samp_temp > 0.f) {
-        KL(KC_OTHER, 4.0 * 42 * c->cur_B * g.dec_vocab,
-           launch_sample_select(c->d_logits, c->cur_B, g.dec_vocab, c->samp_temp, c->samp_top_p, c->d_seed, c->d_step,
-                                c->d_probs, c->d_chosen, s));
+        KL(KC_OTHER, 4.0 * 4 * c->cur_B * g.dec_vocab,
+           launch_sample_select(c->d_logits, c->cur_B, g.dec_vocab, c->samp_temp, c->samp_top_p, c->d_seed, c->d_step, c->d_pval,
+                                c->d_pidx, c->d_probs, c->d_cand_i, c->d_cand_n, c->d_zpart, c->d_spart, c->d_chosen, s));
         chosen = c->d_chosen;
     } else {
         KL(KC_OTHER, 4.0 * c->cur_B * g.dec_vocab, launch_argmax_partial(c->d_logits, c->cur_B, g.dec_vocab, c->d_pval, c->d_pidx, s));
@@ -782,7 +787,8 @@ extern "C" int opus_debug_sample(opus_ctx *c, const float *d_logits, int32_t B, 
     hipStream_t s = (hipStream_t)stream;
     HIPC(hipMemcpyAsync(c->d_seed, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(c->d_plan, &step, sizeof(step), hipMemcpyHostToDevice, s));
-    HIPC(launch_sample_select(d_logits, B, c->cfg.dec_vocab, temperature, top_p, c->d_seed, c->d_plan, c->d_probs, d_tokens, s));
+    HIPC(launch_sample_select(d_logits, B, c->cfg.dec_vocab, temperature, top_p, c->d_seed, c->d_plan, c->d_pval, c->d_pidx,
+                              c->d_probs, c->d_cand_i, c->d_cand_n, c->d_zpart, c->d_spart, d_tokens, s));
     HIPC(hipStreamSynchronize(s));   // seed / step are host temporaries
     return OPUS_OK;
 }

@@ -91,7 +91,8 @@ hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, in
                               int n_tok, int H, int V, const half_t *emb, const int32_t *plan, int Tout,
                               int left_pad, half_t *out, uint8_t *mask_out, int32_t *pos_out, hipStream_t s);
 hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, const uint64_t *seed,
-                                const int32_t *step, float *probs, int32_t *chosen, hipStream_t s);
+                                const int32_t *step, float *pmax, int32_t *pidx, float *cand_p, int32_t *cand_i,
+                                int32_t *cand_n, float *zpart, float *spart, int32_t *chosen, hipStream_t s);
 hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, const int32_t *chosen, int B, const int32_t *eos, int n_eos, int pad_id,
                               int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
                               int32_t *next_tok, int32_t *n_unfinished, hipStream_t s);

@@ -478,74 +478,143 @@ __device__ __forceinline__ float block_max256(float v, float *scratch) {
     return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
 }
 
-__global__ __launch_bounds__(256) void sample_select_kernel(const float *__restrict__ logits, int V, float inv_temp,
-                                                            float top_p, const uint64_t *__restrict__ seed_p, const int32_t *__restrict__ step,
-                                                            float *__restrict__ probs, int32_t *__restrict__ chosen) {
+// Stage 1 (APART workgroups per row, after argmax_partial has left the per-part maxima): p_i = exp(l_i/T - max),
+// per-part sum, and a COMPACTED candidate list per part in index order.  A token with p_i <= (1 - top_p) / V can
+// never be kept (Z >= 1 because the arg-max token has p = 1, so the ascending cumulative mass up to it is at most
+// V * p_i <= (1 - top_p) * Z): only the others - a handful at the reference's temperature 0.1 - go to stage 2.
+__global__ __launch_bounds__(256) void sample_stage1_kernel(const float *__restrict__ logits, int V, float inv_temp, float top_p,
+                                                            const float *__restrict__ pmax, float *__restrict__ cand_p,
+                                                            int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n,
+                                                            float *__restrict__ zpart, float *__restrict__ spart) {
+    __shared__ float scratch[4];
+    __shared__ int s_cnt[257];
+    const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const float *row = logits + (int64_t)b * V;
+    float gmax = pmax[b * APART];
+    for (int k = 1; k < APART; ++k) gmax = fmaxf(gmax, pmax[b * APART + k]);
+    gmax *= inv_temp;
+    const int per = ((V + APART - 1) / APART + 3) & ~3;          // same partition as argmax_partial
+    const int lo = part * per, hi = (lo + per < V ? lo + per : V);
+    const int tper = (per + 255) / 256;                           // contiguous elements per thread
+    const int i0 = lo + tid * tper, i1 = (i0 + tper < hi ? i0 + tper : hi);
+    const float thr = (1.0f - top_p) / (float)V;
+    float z = 0.f, small = 0.f;
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) {
+        const float p = __expf(row[i] * inv_temp - gmax);
+        z += p;
+        if (p > thr) ++cnt; else small += p;
+    }
+    s_cnt[tid + 1] = cnt;
+    if (tid == 0) s_cnt[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= 256; ++t) s_cnt[t] += s_cnt[t - 1];
+    __syncthreads();
+    int w = s_cnt[tid];
+    float *cp = cand_p + ((int64_t)b * APART + part) * per;
+    int32_t *ci = cand_i + ((int64_t)b * APART + part) * per;
+    for (int i = i0; i < i1; ++i) {
+        const float p = __expf(row[i] * inv_temp - gmax);
+        if (p > thr) { cp[w] = p; ci[w] = i; ++w; }
+    }
+    z = block_sum256(z, scratch);
+    small = block_sum256(small, scratch);
+    if (tid == 0) {
+        cand_n[b * APART + part] = s_cnt[256];
+        zpart[b * APART + part] = z;
+        spart[b * APART + part] = small;
+    }
+}
+
+// Stage 2 (one workgroup per row): nucleus threshold by bisection over the candidates, then the draw.
+constexpr int SAMPLE_LDS_CAP = 6144;
+__global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, const uint64_t *__restrict__ seed_p,
+                                                            const int32_t *__restrict__ step, const float *__restrict__ cand_p,
+                                                            const int32_t *__restrict__ cand_i, const int32_t *__restrict__ cand_n,
+                                                            const float *__restrict__ zpart, const float *__restrict__ spart,
+                                                            int32_t *__restrict__ chosen) {
     __shared__ float scratch[4];
     __shared__ float s_pref[257];
+    __shared__ int s_off[APART + 1];
+    __shared__ float s_p[SAMPLE_LDS_CAP];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float *row = logits + (int64_t)b * V;
-    float *pr = probs + (int64_t)b * V;
-    float mx = -INFINITY;
-    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i] * inv_temp);
-    mx = block_max256(mx, scratch);
-    float z = 0.f;
-    for (int i = tid; i < V; i += 256) {
-        const float p = __expf(row[i] * inv_temp - mx);
-        pr[i] = p;
-        z += p;
+    const int per = ((V + APART - 1) / APART + 3) & ~3;
+    if (tid == 0) {
+        s_off[0] = 0;
+        for (int k = 0; k < APART; ++k) s_off[k + 1] = s_off[k] + cand_n[b * APART + k];
     }
-    const float Z = block_sum256(z, scratch);
+    __syncthreads();
+    const int nc = s_off[APART];
+    float Z = 0.f, S0 = 0.f;
+    for (int k = 0; k < APART; ++k) { Z += zpart[b * APART + k]; S0 += spart[b * APART + k]; }   // fixed order
     const float cut = (1.0f - top_p) * Z;
-    // bisection: invariant  S_le(lo) <= cut < S_le(hi)  with S_le(x) = sum of p_i <= x; S_le(1) = Z > cut
+    // candidate c (global order = index order) lives at part k, slot c - s_off[k]
+    auto cand = [&](int c, int &idx) -> float {
+        int k = 0;
+        while (c >= s_off[k + 1]) ++k;
+        const int64_t o = ((int64_t)b * APART + k) * per + (c - s_off[k]);
+        idx = cand_i[o];
+        return cand_p[o];
+    };
+    const bool in_lds = nc <= SAMPLE_LDS_CAP;
+    if (in_lds)
+        for (int c = tid; c < nc; c += 256) { int id; s_p[c] = cand(c, id); }
+    __syncthreads();
+    auto pval = [&](int c) -> float { int id; return in_lds ? s_p[c] : cand(c, id); };
+    // bisection: S_le(x) = S0 + sum of candidates <= x ; invariant S_le(lo) <= cut < S_le(hi)
     float lo = 0.f, hi = 1.0f;
     for (int it = 0; it < 40; ++it) {
         const float mid = 0.5f * (lo + hi);
         float s = 0.f;
-        for (int i = tid; i < V; i += 256) {
-            const float p = pr[i];
+        for (int c = tid; c < nc; c += 256) {
+            const float p = pval(c);
             s += p <= mid ? p : 0.f;
         }
-        s = block_sum256(s, scratch);
+        s = S0 + block_sum256(s, scratch);
         if (s > cut) hi = mid; else lo = mid;
     }
-    // kept set = { p_i > lo }; contiguous index chunks per thread, CDF inversion in index order
-    const int per = (V + 255) / 256;
-    const int i0 = tid * per, i1 = (i0 + per < V ? i0 + per : V);
+    // kept = candidates with p > lo; CDF inversion in index order over contiguous chunks of the candidate list
+    const int cper = (nc + 255) / 256;
+    const int c0 = tid * cper, c1 = (c0 + cper < nc ? c0 + cper : nc);
     float mine = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        const float p = pr[i];
+    for (int c = c0; c < c1; ++c) {
+        const float p = pval(c);
         mine += p > lo ? p : 0.f;
     }
     s_pref[tid + 1] = mine;
     if (tid == 0) s_pref[0] = 0.f;
     __syncthreads();
     if (tid == 0)
-        for (int t = 1; t <= 256; ++t) s_pref[t] += s_pref[t - 1];     // fixed order
+        for (int t = 1; t <= 256; ++t) s_pref[t] += s_pref[t - 1];
     __syncthreads();
     const float total = s_pref[256];
-    uint64_t h = splitmix64(*seed_p ^ (0x9E3779B97F4A7C15ull * (uint64_t)(b + 1)) ^ ((uint64_t)(*step + 1) << 32));
-    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);               // [0, 1)
-    const float target = u * total;
+    const uint64_t h = splitmix64(*seed_p ^ (0x9E3779B97F4A7C15ull * (uint64_t)(b + 1)) ^ ((uint64_t)(*step + 1) << 32));
+    const float target = (float)(h >> 40) * (1.0f / 16777216.0f) * total;          // u in [0,1)
     if (s_pref[tid] <= target && target < s_pref[tid + 1]) {
         float run = s_pref[tid];
         int pick = -1, last_kept = -1;
-        for (int i = i0; i < i1; ++i) {
-            const float p = pr[i];
+        for (int c = c0; c < c1; ++c) {
+            int id;
+            const float p = cand(c, id);
             if (p > lo) {
-                last_kept = i;
+                last_kept = id;
                 run += p;
-                if (target < run) { pick = i; break; }
+                if (target < run) { pick = id; break; }
             }
         }
         chosen[b] = pick >= 0 ? pick : last_kept;
     }
-    if (tid == 0 && !(target < total)) chosen[b] = 0;                       // total == 0 cannot happen (max p = 1)
 }
+
 hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, const uint64_t *seed,
-                                const int32_t *step, float *probs, int32_t *chosen, hipStream_t s) {
-    hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(256), 0, s, logits, V, 1.0f / temperature, top_p, seed, step,
-                       probs, chosen);
+                                const int32_t *step, float *pmax, int32_t *pidx, float *cand_p, int32_t *cand_i,
+                                int32_t *cand_n, float *zpart, float *spart, int32_t *chosen, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(APART, B), dim3(256), 0, s, logits, V, pmax, pidx);
+    hipLaunchKernelGGL(sample_stage1_kernel, dim3(APART, B), dim3(256), 0, s, logits, V, 1.0f / temperature, top_p, pmax, cand_p,
+                       cand_i, cand_n, zpart, spart);
+    hipLaunchKernelGGL(sample_stage2_kernel, dim3(B), dim3(256), 0, s, V, top_p, seed, step, cand_p, cand_i, cand_n, zpart, spart,
+                       chosen);
     return hipGetLastError();
 }
 
