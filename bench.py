@@ -250,9 +250,10 @@ def main():
         ms, n, by = model.timing_get("skinny_gemm")
         parts = {k: model.timing_get(k) for k in ("tile_gemm", "attn_prefill", "attn_decode", "other")}
         model.timing(False)
+        ach = by / (ms * 1e-3) / 1e9 if ms > 0 else None           # no skinny launch at this batch size
         res["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny_kernel (weight-streaming GEMM, M<=16)",
-                           "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": pmc_traffic() if ach else None,
                            "algorithmic_bytes_per_launch": by / max(n, 1),
                            "launches_per_step": n, "avg_launch_us": 1e3 * ms / max(n, 1),
                            "algorithmic_bytes_per_step": by,

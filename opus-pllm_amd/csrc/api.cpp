@@ -413,7 +413,10 @@ static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const 
 static int gemm_norm(opus_ctx *c, hipStream_t s, const float *X, float eps, half_t *scratch, const half_t *W, int M, int N,
                      int K, int epi, void *C, int64_t ldc, int out_f32) {
     static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;
-    if (M <= SKINNY_MAX_M || (M <= MID_MAX_M && !no_mid))
+    static const bool mid_v1 = getenv("OPUS_MID_V1") != nullptr;
+    // 17..64 rows with a wide output (wgu, lm_head): the wide kernel wants fp16 activations, so norm separately
+    const bool wide = M > SKINNY_MAX_M && N >= 16384 && !mid_v1;
+    if (M <= SKINNY_MAX_M || (M <= MID_MAX_M && !no_mid && !wide))
         return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
     KL(KC_OTHER, 6.0 * M * K, launch_rmsnorm(X, nullptr, eps, M, K, scratch, s));
     return gemm(c, s, scratch, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);

@@ -8,6 +8,7 @@
 // The new key/value are used from LDS, so nothing depends on in-launch global visibility.
 // slot = T0 + *step is read from device memory so the same launch can be replayed from a hipGraph.
 #include "common.h"
+#include <cstdlib>
 
 namespace opus {
 
@@ -238,7 +239,8 @@ static hipError_t launch_hd(const half_t *qkv, const float *cs, const int32_t *k
                             float scale, half_t *out, hipStream_t s) {
     const int G = nh / nkv;
     // grouped form only when the per-head form would already fill the chip several times over
-    const bool grouped = G > 1 && (int64_t)B * nkv >= 1024;
+    static const int group_min = getenv("OPUS_ATTN_GROUP_MIN") ? atoi(getenv("OPUS_ATTN_GROUP_MIN")) : 256;   // tuning aid
+    const bool grouped = G > 1 && (int64_t)B * nkv >= group_min;
 #define OPUS_GO(GPV) return launch_t<HD, GPV>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s)
     if (!grouped) OPUS_GO(1);
     switch (G) {

@@ -702,131 +702,155 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmParams p, int ksplit)
 }
 
 // ------------------------------------------------------------------------------------------------
-// big: 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 each = 8 x 4 MFMA tiles, 128 accumulator
-// registers), K streamed in 32-deep stages through a 4-slot LDS ring (4 x 32 KB = 128 KB) filled by
-// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  Three stages are kept in
-// flight across the single raw s_barrier per stage with a COUNTED s_waitcnt vmcnt (never 0 in the
-// steady state): cdna_hip_programming.md "Pipelining across barriers" / T3+T4.
-//   A stage image [256 rows][4 x 16 B], the 16-B chunk c of row r stored in slot c ^ T[(r>>2)&3],
-//   T = {0,3,2,1}: conflict-free for the 16-lane groups of ds_read_b128 (rows 64 B apart).  glds
-//   writes LDS linearly, so the permutation is applied to the per-lane SOURCE address (rule 21).
-//   B stage image = the 16 weight panels' 1-KB half blocks, already in fragment order: linear.
-// Hazards: RAW - a stage is read only after every wave's vmcnt for it and the barrier; WAR - the
-// slot refilled in iteration ks was last read in iteration ks-1, and the refill is issued after the
-// barrier of iteration ks, which every wave reaches only after finishing those reads.
-constexpr int GBM = 256, GBN = 256, GBK = 32;
+// ring: the LDS-DMA pipelined MFMA kernel.  8 waves (2 x 4), wave tile (16 TM) x (16 TN), workgroup tile
+// BM x BN = (32 TM) x (64 TN), K streamed in 32-deep stages through an NS-slot LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write).  NS-1 stages stay in flight across the single
+// raw s_barrier per stage behind a COUNTED s_waitcnt vmcnt (never 0 in the steady state):
+// cdna_hip_programming.md "Pipelining across barriers" / T3+T4.  Instances:
+//   <8,4,4>  256 x 256, 4 x 32 KB : encoder / prefill / batched-projector GEMMs (MFMA-bound, 1.0-1.1 PFLOP/s)
+//   <4,2,6>  128 x 128, 6 x 16 KB : 64 < M <= 128 (weight-streaming, k-parts when N is small)
+//   <2,2,8>   64 x 128, 8 x 12 KB : 16 < M <= 64 batched decode (weight-streaming, 7 stages in flight)
+// A stage image [BM rows][4 x 16 B], the 16-B chunk c of row r stored in slot c ^ T[(r>>2)&3], T = {0,3,2,1}:
+// conflict-free for the 16-lane groups of ds_read_b128 (rows 64 B apart).  glds writes LDS linearly, so the
+// permutation is applied to the per-lane SOURCE address (rule 21).  B stage image = the weight panels' 1-KB half
+// blocks, already in fragment order: linear.  Every wave issues the same number of glds per stage (when the A
+// image has fewer than 8 pieces, waves repeat a piece: identical bytes to the same place) so one vmcnt count fits all.
+// Hazards: RAW - a stage is read only after every wave's vmcnt for it and the barrier; WAR - the slot refilled in
+// iteration ks was last read in iteration ks-1, those reads are retired (lgkmcnt(0)) before the barrier of iteration
+// ks, and the refill is issued after it.
+// k-parts (gridDim.y > 1): raw fp32 slabs, combined by splitk_reduce_kernel in a fixed order.
+constexpr int GBK = 32;
 
 __device__ __forceinline__ int aswz(int row) { return (-(row >> 2)) & 3; }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_big_kernel(GemmParams p, int tiles_m, int tiles_n) {
+template <int N>
+__device__ __forceinline__ void vmcnt_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM, int TN, int NS, int EPI>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_m, int tiles_n, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 32 * TM, BN = 64 * TN;
+    constexpr int A_BYTES = BM * 64, STAGE = A_BYTES + BN * 64;
+    constexpr int NA = BM / 16, CA = NA >= 8 ? NA / 8 : 1;           // 1-KB A pieces per stage / per wave
+    constexpr int CB = BN / 128;                                     // 1-KB B pieces per wave (BN/16 panels over 8 waves)
+    constexpr int P = CA + CB;                                       // glds per wave per stage
+    static_assert(BN % 128 == 0 && (NS - 1) * P <= 63, "tile configuration");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, li = lane & 15;
     int bid = blockIdx.x;
-    {
+    {   // XCD-aware: consecutive workgroup ids are dealt round-robin over the 8 XCDs; give each XCD a contiguous run
         const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
         bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     }
-    // Grouped tile order inside each XCD's run: GM tile-rows are walked column by column, so the ~32
-    // tiles an XCD works on at one time form a compact 2-D patch (8 x 4) that shares A rows 4 ways and
-    // weight panels 8 ways in that XCD's L2, instead of a 1 x 32 strip that streams all of W per row.
+    // Grouped tile order inside each XCD's run: GM tile-rows are walked column by column, so the ~32 tiles an XCD
+    // works on at one time form a compact 2-D patch sharing A rows and weight panels in that XCD's L2.
     constexpr int GM = 8;
     const int per_group = GM * tiles_n;
     const int grp = bid / per_group, rem_id = bid - grp * per_group;
     const int rows_here = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;
     const int tm = grp * GM + rem_id % rows_here, tn = rem_id / rows_here;
-    const int m0 = tm * GBM, n0 = tn * GBN;
-    const int KS = p.K / GBK, KT64 = p.K >> 6;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KS_all = p.K / GBK, KT64 = p.K >> 6;
+    const int ky = blockIdx.y;
+    const int s0 = (int)((int64_t)KS_all * ky / ksplit), s1 = (int)((int64_t)KS_all * (ky + 1) / ksplit);
+    const int KS = s1 - s0;
     const int npanels = (p.N + 15) >> 4;
 
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
-    const half_t *srcA[2], *srcB[2];
+    const half_t *srcA[CA], *srcB[CB];
+    int ldsA[CA];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rl = 16 * (2 * wave + j) + (lane >> 2);           // row inside the tile
+    for (int j = 0; j < CA; ++j) {
+        const int piece = (wave * CA + j) % NA;                      // 16 rows x 64 B
+        const int rl = 16 * piece + (lane >> 2);                     // row inside the tile
         int row = m0 + rl;
         row = row < p.M ? row : p.M - 1;
-        srcA[j] = p.A + (int64_t)row * p.lda + (((lane & 3) ^ aswz(rl)) << 3);
-        int pn = (n0 >> 4) + 2 * wave + j;
+        srcA[j] = p.A + (int64_t)row * p.lda + (((lane & 3) ^ aswz(rl)) << 3) + (int64_t)s0 * GBK;
+        ldsA[j] = piece * 1024;
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        int pn = (n0 >> 4) + wave * CB + j;
         pn = pn < npanels ? pn : npanels - 1;
         srcB[j] = p.W + ((int64_t)pn * KT64) * 1024 + lane * 8;
     }
-    constexpr int NSLOT = 4;   // 4 x 32 KB ring
-    auto stage_load = [&](int ks) {
-        char *base = smem + (ks % NSLOT) * 32768;
+    auto stage_load = [&](int ks) {                                   // ks relative to s0
+        char *base = smem + (ks % NS) * STAGE;
+        const int ka = s0 + ks;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + (int64_t)ks * GBK), (lptr_t)(base + (2 * wave + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (int64_t)(ks >> 1) * 1024 + (ks & 1) * 512),
-                                             (lptr_t)(base + 16384 + (2 * wave + j) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < CA; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + (int64_t)ks * GBK), (lptr_t)(base + ldsA[j]), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (int64_t)(ka >> 1) * 1024 + (ka & 1) * 512),
+                                             (lptr_t)(base + A_BYTES + (wave * CB + j) * 1024), 16, 0, 0);
     };
 
-    f4 acc[8][4];
+    f4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane LDS read offsets inside a stage
-    int aoff[8];
+    int aoff[TM];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int rl = wm * 128 + i * 16 + li;
+    for (int i = 0; i < TM; ++i) {
+        const int rl = wm * (16 * TM) + i * 16 + li;
         aoff[i] = rl * 64 + ((g ^ aswz(rl)) << 4);
     }
-    const int boff = 16384 + (wn * 4) * 1024 + lane * 16;
+    const int boff = A_BYTES + (wn * TN) * 1024 + lane * 16;
 
-    // Schedule (one raw barrier per 32-deep stage, three stages of LDS-DMA in flight across it).
-    // Iteration ks: wait for this wave's part of stage ks+1 (stages ks+2, ks+3 stay in flight) and retire
-    // its fragment reads of stage ks -> barrier (now stage ks+1 is complete and slot ks is free) ->
-    // refill slot ks with stage ks+4 -> issue the fragment reads of stage ks+1 into the second register
-    // set -> MFMAs of stage ks (they overlap those reads).  A two-group half-stage stagger with a 5-slot
-    // ring (MI355X_MICROARCH.md "Two waves per SIMD" item 9) measured the same 1.05-1.1 PF/s and was dropped.
-    auto wait_glds = [&](int rem) {   // rem = stages issued after the one being waited for (4 glds each)
-        if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Iteration ks: wait for this wave's part of stage ks+1 (the later ones stay in flight) and retire its fragment
+    // reads of stage ks -> barrier (stage ks+1 complete, slot ks free) -> refill slot ks with stage ks+NS -> issue the
+    // fragment reads of stage ks+1 into the second register set -> MFMAs of stage ks (they overlap those reads).
+    auto wait_glds = [&](int rem) {   // rem = stages issued after the one being waited for
+        switch (rem) {
+            case 0: vmcnt_wait<0>(); break;
+            case 1: vmcnt_wait<P>(); break;
+            case 2: vmcnt_wait<(NS > 2 ? 2 : 1) * P>(); break;
+            case 3: vmcnt_wait<(NS > 3 ? 3 : 1) * P>(); break;
+            case 4: vmcnt_wait<(NS > 4 ? 4 : 1) * P>(); break;
+            case 5: vmcnt_wait<(NS > 5 ? 5 : 1) * P>(); break;
+            case 6: vmcnt_wait<(NS > 6 ? 6 : 1) * P>(); break;
+            default: vmcnt_wait<(NS > 7 ? 7 : 1) * P>(); break;
+        }
     };
-    auto read_frags = [&](int ks, h8 (&af)[8], h8 (&bf)[4]) {
-        const char *base = smem + (ks % NSLOT) * 32768;
+    auto read_frags = [&](int ks, h8 (&af)[TM], h8 (&bf)[TN]) {
+        const char *base = smem + (ks % NS) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const h8 *>(base + aoff[i]);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8 *>(base + aoff[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const h8 *>(base + boff + j * 1024);
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8 *>(base + boff + j * 1024);
     };
-    auto mfmas = [&](const h8 (&af)[8], const h8 (&bf)[4]) {
+    auto mfmas = [&](const h8 (&af)[TM], const h8 (&bf)[TN]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
         __builtin_amdgcn_s_setprio(0);
     };
     const int last = KS - 1;
     auto issued_upto = [&](int x) { return x < last ? x : last; };
-    auto step = [&](int ks, const h8 (&ca)[8], const h8 (&cb)[4], h8 (&na)[8], h8 (&nb)[4]) {
+    auto step = [&](int ks, const h8 (&ca)[TM], const h8 (&cb)[TN], h8 (&na)[TM], h8 (&nb)[TN]) {
         if (ks + 1 < KS) {
-            wait_glds(issued_upto(ks + 3) - (ks + 1));
+            wait_glds(issued_upto(ks + NS - 1) - (ks + 1));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // WAR: this wave's reads of slot ks are done
             __builtin_amdgcn_s_barrier();
-            if (ks + 4 < KS) stage_load(ks + 4);
+            if (ks + NS < KS) stage_load(ks + NS);
             read_frags(ks + 1, na, nb);
         }
         mfmas(ca, cb);
     };
-    h8 a0[8], b0[4], a1[8], b1[4];
-    stage_load(0);
-    if (KS > 1) stage_load(1);
-    if (KS > 2) stage_load(2);
-    if (KS > 3) stage_load(3);
-    wait_glds(issued_upto(3));
+    h8 a0[TM], b0[TN], a1[TM], b1[TN];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < KS) stage_load(s);
+    wait_glds(issued_upto(NS - 1));
     __builtin_amdgcn_s_barrier();
     read_frags(0, a0, b0);
     for (int ks = 0; ks < KS; ks += 2) {
@@ -834,16 +858,37 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmParams p, int tiles_m
         if (ks + 1 < KS) step(ks + 1, a1, b1, a0, b0);
     }
 
+    if (ksplit > 1) {
+        float *slab = p.ws + (int64_t)ky * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + li;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (16 * TM) + i * 16 + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = n0 + wn * (16 * TN) + j * 16 + 4 * g;
+                if ((p.N & 3) == 0 && nb + 3 < p.N) {
+                    *reinterpret_cast<float4 *>(slab + (int64_t)m * p.N + nb) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) slab[(int64_t)m * p.N + nb + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (16 * TM) + i * 16 + li;
         if (m >= p.M) continue;
         if (EPI == EPI_SILU_GU16) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wn * 64 + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
+            for (int jj = 0; jj < TN / 2; ++jj)
+                store4<EPI>(p, m, n0 + wn * (16 * TN) + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) store4<EPI>(p, m, n0 + wn * (16 * TN) + j * 16 + 4 * g, acc[i][j], acc[i][j]);
         }
     }
 }
@@ -885,6 +930,186 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
     if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
     else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
 }
+
+template <int EPI>
+static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s) {
+    const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, p, ks);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// wide (16 < M <= 64, fp16 activations): batched-decode weight streaming with ONE barrier per 512 k.
+// Workgroup = 8 waves = 8 weight panels (128 output columns) x all M rows x one k-part.  The [M x 512]
+// activation slice of a stage is brought into LDS by LDS-DMA (8 x 1 KB pieces per wave, a full stage ahead,
+// double-buffered: 2 x 64 KB at M = 64) and stays put while every wave streams ITS panel's weights for that
+// slice straight from HBM through a 4-chunk register ring (non-temporal), so the vector-memory queue carries
+// weights and nothing waits on a barrier for 64 MFMAs at a time.  vmcnt counts LDS-DMA and register loads
+// together in issue order: the stage's DMA is issued before the 16 weight loads of the stage, of which at
+// most 8 are still in flight at the end, so `s_waitcnt vmcnt(8)` retires the DMA without draining the ring.
+template <int MT, int EPI>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MP = 16 * MT;
+    constexpr int SC = 8;                                            // 64-k chunks per stage
+    constexpr int CIMG = MP * 128;                                   // bytes of one chunk image [MP][64] fp16
+    constexpr int STAGE = SC * CIMG;
+    constexpr int NPIECE = SC * MP / 8;                              // 1-KB DMA pieces per stage (8 rows x 128 B)
+    constexpr int PW = NPIECE / 8;                                   // per wave (MT = 2: 4, MT = 4: 8)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int chunks = p.K >> 6;
+    const int npanels = (p.N + 15) >> 4;
+    int panel = blockIdx.x * 8 + wave;
+    const bool panel_ok = panel < npanels;
+    panel = panel_ok ? panel : npanels - 1;
+    const int ky = blockIdx.y;
+    const int c0 = (int)((int64_t)chunks * ky / ksplit), c1 = (int)((int64_t)chunks * (ky + 1) / ksplit);
+    const half_t *wp = p.W + ((int64_t)panel * chunks) * 1024 + lane * 8;
+
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    // DMA piece q of a stage: chunk = q / (MP/8), rows 8*(q % (MP/8)) .. +7; lane -> row + lane/8, 16-B slot lane%8
+    // holding source chunk16 = slot ^ ((row>>1)&7)  (the swizzle goes on the SOURCE address, rule 21)
+    int pc[PW];
+    const half_t *psrc[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int q = wave * PW + j;
+        const int ch = q / (MP / 8), r = 8 * (q % (MP / 8)) + (lane >> 3);
+        int row = r < p.M ? r : p.M - 1;
+        pc[j] = ch;
+        psrc[j] = p.A + (int64_t)row * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+    }
+    auto dma_stage = [&](int buf, int c) {                            // chunks c .. c+SC-1 (clamped to the k-part)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int cc = c + pc[j] < c1 ? c + pc[j] : c1 - 1;
+            const int q = wave * PW + j;
+            __builtin_amdgcn_global_load_lds((gptr_t)(psrc[j] + (int64_t)cc * 64),
+                                             (lptr_t)(smem + buf * STAGE + q * 1024), 16, 0, 0);
+        }
+    };
+
+    f4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    h8 wl[U], wh[U];
+    auto w_load = [&](int u, int c) {
+        if (c < c1) {
+            const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)c * 1024);
+            wl[u] = __builtin_nontemporal_load(ptr);
+            wh[u] = __builtin_nontemporal_load(ptr + 64);
+        }
+    };
+    int aoff[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = 16 * i + li;
+        aoff[i] = r * 128 + ((g ^ ((r >> 1) & 7)) << 4);             // second k-step: ^ (4 << 4) on the chunk index
+    }
+
+    dma_stage(0, c0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) w_load(u, c0 + u);
+    int buf = 0;
+    for (int cs = c0; cs < c1; cs += SC, buf ^= 1) {
+        // the DMA of this stage was issued before the (at most) 8 weight loads still in flight
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's fragment reads of the other buffer
+        __builtin_amdgcn_s_barrier();
+        if (cs + SC < c1) dma_stage(buf ^ 1, cs + SC);
+        const char *base = smem + buf * STAGE;
+#pragma unroll
+        for (int u8 = 0; u8 < SC; ++u8) {
+            const int c = cs + u8;
+            if (c < c1) {                                            // wave-uniform
+                const int u = u8 & (U - 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const h8 a0 = *reinterpret_cast<const h8 *>(base + u8 * CIMG + aoff[i]);
+                    const h8 a1 = *reinterpret_cast<const h8 *>(base + u8 * CIMG + (aoff[i] ^ 64));
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], a0, acc[i], 0, 0, 0);   // C^T tile
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], a1, acc[i], 0, 0, 0);
+                }
+                w_load(u, c + U);
+            }
+        }
+    }
+
+    if (ksplit > 1) {
+        float *slab = p.ws + (int64_t)ky * p.M * p.N;
+        if (panel_ok) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = 16 * i + li, nb = panel * 16 + 4 * g;
+                if (m < p.M) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) slab[(int64_t)m * p.N + nb + r] = acc[i][r];
+                }
+            }
+        }
+        return;
+    }
+    if (EPI == EPI_SILU_GU16) {
+        // panels alternate gate / up: odd waves hand their tile to the even wave on their left (LDS is free now)
+        __syncthreads();
+        float *xch = reinterpret_cast<float *>(smem);
+        if (wave & 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[(((wave >> 1) * MT + i) * 4 + r) * 64 + lane] = acc[i][r];
+        }
+        __syncthreads();
+        if ((wave & 1) == 0 && panel_ok) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = 16 * i + li;
+                if (m >= p.M) continue;
+                f4 up;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) up[r] = xch[(((wave >> 1) * MT + i) * 4 + r) * 64 + lane];
+                store4<EPI>(p, m, panel * 16 + 4 * g, acc[i], up);
+            }
+        }
+    } else if (panel_ok) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = 16 * i + li;
+            if (m < p.M) store4<EPI>(p, m, panel * 16 + 4 * g, acc[i], acc[i]);
+        }
+    }
+}
+
+template <int MT, int EPI>
+static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
+    const int blocks = cdiv((p.N + 15) >> 4, 8), chunks = p.K / 64;
+    int ks = 1;
+    if (p.ws && blocks < 200) {                                      // few column groups: split K over workgroups
+        ks = cdiv(256, blocks);
+        ks = ks > 8 ? 8 : ks;
+        if (ks > chunks / 8) ks = chunks / 8;
+        while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
+        if (ks < 1) ks = 1;
+    }
+    const int lds = 2 * 8 * 16 * MT * 128;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_kernel<MT, EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (ea != hipSuccess) return ea;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_wide_kernel<MT, EPI>), dim3(blocks, ks), dim3(512), lds, s, p, ks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return launch_reduce<EPI>(p, ks, s);
+}
+
 
 template <int MT, int EPI, bool NORM>
 static hipError_t launch_mid_t(const GemmParams &p, hipStream_t s) {
@@ -929,6 +1154,36 @@ static hipError_t launch_mid_e(const GemmParams &p, hipStream_t s) {
 }
 
 template <int EPI>
+static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s);
+
+// ring kernel launcher; allow_split: choose k-parts so that ~256-512 workgroups stream the weights
+template <int TM, int TN, int NS, int EPI>
+static hipError_t launch_ring(const GemmParams &p, hipStream_t s, bool allow_split) {
+    constexpr int BM = 32 * TM, BN = 64 * TN;
+    constexpr int LDS = NS * (BM * 64 + BN * 64);
+    const int bm = cdiv(p.M, BM), bn = cdiv(p.N, BN), KS = p.K / GBK;
+    int ks = 1;
+    if (allow_split && p.ws && bm * bn < 200) {
+        ks = cdiv(256, bm * bn);
+        ks = ks > 16 ? 16 : ks;
+        if (ks > KS / 8) ks = KS / 8;
+        while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
+        if (ks < 1) ks = 1;
+    }
+    static bool attr = false;
+    if (!attr) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ring_kernel<TM, TN, NS, EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (ea != hipSuccess) return ea;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<TM, TN, NS, EPI>), dim3(bm * bn, ks), dim3(512), LDS, s, p, bm, bn, ks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return launch_reduce<EPI>(p, ks, s);
+}
+
+template <int EPI>
 static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     const int tm = cdiv(p.M, TBM), tn = cdiv(p.N, TBN);
     static bool attr_set = false;
@@ -938,21 +1193,9 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
         if (ea != hipSuccess) return ea;
         attr_set = true;
     }
-    {   // enough 256 x 256 tiles to fill the chip: the 8-wave LDS-DMA pipeline
-        const int bm = cdiv(p.M, GBM), bn = cdiv(p.N, GBN);
-        static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr;   // A/B aid
-        if (!no_big && (int64_t)bm * bn >= 192) {
-            static bool big_attr = false;
-            if (!big_attr) {
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_big_kernel<EPI>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-                if (ea != hipSuccess) return ea;
-                big_attr = true;
-            }
-            hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(bm * bn), dim3(512), 131072, s, p, bm, bn);
-            return hipGetLastError();
-        }
-    }
+    static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr;   // A/B aid
+    if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192)   // enough 256 x 256 tiles to fill the chip
+        return launch_ring<8, 4, 4, EPI>(p, s, false);
     // Too few output tiles to fill 256 CUs (B = 1 prefill, single-protein encoder): split K so that
     // ~256-320 workgroups stream the weights, at least 4 k-tiles each, slabs within the workspace.
     const int ntile = tm * tn, KT = p.K / TBK;
@@ -978,6 +1221,7 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
     const bool skinny = p.M <= SKINNY_MAX_M;
     static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;   // A/B aid
     const bool mid = !skinny && p.M <= MID_MAX_M && !no_mid;
+    static const bool mid_v1 = getenv("OPUS_MID_V1") != nullptr;        // A/B aid: 4-panel kernel for every mid shape
     if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;
     if (p.Af && !skinny && !mid) return hipErrorInvalidValue;   // fused norm: skinny and mid kernels only
     if (p.Af && p.epi == EPI_GELU) return hipErrorInvalidValue;
@@ -993,6 +1237,21 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
             case EPI_NONE: return launch_skinny_e<EPI_NONE, false>(p, s);
             case EPI_GELU: return launch_skinny_e<EPI_GELU, false>(p, s);
             case EPI_SILU_GU16: return launch_skinny_e<EPI_SILU_GU16, false>(p, s);
+        }
+    } else if (mid && !p.Af && !mid_v1 && p.N >= 16384) {
+        // wide outputs (wgu, lm_head): one barrier per 512 k, weights through per-wave register rings
+        const bool m2 = p.M <= 32;
+        switch (p.epi) {
+            case EPI_NONE: return m2 ? launch_wide<2, EPI_NONE>(p, s) : launch_wide<4, EPI_NONE>(p, s);
+            case EPI_GELU: return m2 ? launch_wide<2, EPI_GELU>(p, s) : launch_wide<4, EPI_GELU>(p, s);
+            case EPI_SILU_GU16: return m2 ? launch_wide<2, EPI_SILU_GU16>(p, s) : launch_wide<4, EPI_SILU_GU16>(p, s);
+        }
+    } else if (mid && !p.Af && !mid_v1 && p.M > 32) {
+        // narrow outputs at 33..64 rows (wo, wd): the LDS-DMA ring with a 128 x 128 tile and k-parts
+        switch (p.epi) {
+            case EPI_NONE: return launch_ring<2, 2, 8, EPI_NONE>(p, s, true);
+            case EPI_GELU: return launch_ring<2, 2, 8, EPI_GELU>(p, s, true);
+            case EPI_SILU_GU16: return launch_ring<2, 2, 8, EPI_SILU_GU16>(p, s, true);
         }
     } else if (mid) {
         if (p.Af) {

@@ -91,6 +91,14 @@ if __name__ == "__main__":
         bench_tile("square 4096", 4096, 4096, 4096, 0)
         bench_tile("square 8192", 8192, 8192, 8192, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mid16":
+        for M in (32, 64):
+            bench("wgu silu (fp16 A)", M, 28672, 4096, 2, False)
+            bench("wqkv (fp16 A)", M, 6144, 4096, 0, False)
+            bench("wo", M, 4096, 4096, 0, False)
+            bench("wd", M, 4096, 14336, 0, False)
+            bench("lm_head (fp16 A)", M, 128256, 4096, 0, False)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mid":
         for M in (32, 64, 128):
             bench("wgu silu+norm", M, 28672, 4096, 2, True)
