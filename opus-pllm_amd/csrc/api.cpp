@@ -93,6 +93,11 @@ struct opus_ctx {
     int g_B = -1, g_T = -1, g_maxnew = -1, g_pad = 0, g_neos = -1;
     const int32_t *g_out = nullptr;
     float g_temp = 0.f, g_top_p = 1.f;
+    // persistent decode-step kernel: per-layer weight table and grid-barrier words (device)
+    StackLayer *d_stack_layers = nullptr;
+    unsigned *d_bar = nullptr;
+    unsigned long long *d_trace = nullptr;
+    bool stack_used = false, g_stack = false;
     // timing
     bool timing = false;
     std::vector<TimeRec> recs;
@@ -257,6 +262,8 @@ extern "C" int opus_ctx_destroy(opus_ctx *c) {
     timing_clear(c);
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->d_stack_layers) (void)hipFree(c->d_stack_layers);
+    if (c->d_bar) (void)hipFree(c->d_bar);
     delete c;
     return OPUS_OK;
 }
@@ -345,6 +352,15 @@ extern "C" int opus_weights_ready(opus_ctx *c) {
         GW(p + "wd", OPUS_F16, (std::vector<int64_t>{H, F}), L.wd);
     }
     GW("dec.lm_head", OPUS_F16, (std::vector<int64_t>{V, H}), c->lm_head);
+    {
+        std::vector<StackLayer> tab(g.dec_layers);
+        for (int l = 0; l < g.dec_layers; ++l) tab[l] = StackLayer{c->dec[l].wqkv, c->dec[l].wo, c->dec[l].wgu, c->dec[l].wd};
+        if (!c->d_stack_layers) HIPC(hipMalloc(&c->d_stack_layers, tab.size() * sizeof(StackLayer)));
+        HIPC(hipMemcpy(c->d_stack_layers, tab.data(), tab.size() * sizeof(StackLayer), hipMemcpyHostToDevice));
+        const size_t bar_words = 1024 + 16 * 1024;                 // counters + 16 "go" words 4 KB apart
+        if (!c->d_bar) HIPC(hipMalloc(&c->d_bar, bar_words * sizeof(unsigned)));
+        HIPC(hipMemset(c->d_bar, 0, bar_words * sizeof(unsigned)));
+    }
     c->resolved = true;
     return OPUS_OK;
 }
@@ -610,6 +626,24 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
     return OPUS_OK;
 }
 
+// OPUS_STACK=1 routes decode steps at batch <= 4 through the single-launch persistent kernel (decode_stack.hip).
+// Opt-in: measured slower than one launch per operator on MI355X ("persistent decode step").
+static bool stack_enabled() {
+    const char *e = getenv("OPUS_STACK");
+    return e && atoi(e) == 1;
+}
+
+// after a synchronize: did a grid barrier of the persistent kernel time out?
+static int stack_check(opus_ctx *c) {
+    if (!c->stack_used) return OPUS_OK;
+    c->stack_used = false;
+    unsigned flag = 0;
+    HIPC(hipMemcpy(&flag, c->d_bar + 2, sizeof(flag), hipMemcpyDeviceToHost));
+    if (!flag) return OPUS_OK;
+    HIPC(hipMemset(c->d_bar, 0, (1024 + 16 * 1024) * sizeof(unsigned)));
+    return fail(OPUS_EHIP, "decode stack: a grid barrier timed out (workgroups not co-resident?); results are invalid");
+}
+
 // One decode step for the token ids in d_tok (device): embeds them, runs the stack at slot T + *step,
 // leaves logits in c->d_logits and advances *step.
 static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
@@ -619,6 +653,37 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
     const int ctx_cap = g.max_prompt + g.max_new_tokens;
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, s));
+    if (stack_enabled() && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap)) {
+        c->stack_used = true;
+        StackParams sp;
+        sp.layers = c->d_stack_layers; sp.n_layers = g.dec_layers; sp.lm_head = c->lm_head;
+        sp.B = B; sp.H = H; sp.F = F; sp.nh = nh; sp.nkv = nkv; sp.V = g.dec_vocab;
+        sp.eps = g.dec_rms_eps; sp.scale = 1.0f / sqrtf((float)hd);
+        sp.x = c->d_xl; sp.qkv = c->d_qkv; sp.ctx = c->d_ctx; sp.act = c->d_act; sp.logits = c->d_logits;
+        sp.cs = c->cs_dec; sp.kstart = c->d_kstart; sp.step = c->d_step; sp.T0 = T;
+        sp.kc = c->kc; sp.vc = c->vc; sp.cache_sl = c->cache_sl; sp.cache_sb = c->cache_sb; sp.cache_sh = c->cache_sh;
+        sp.ctx_cap = ctx_cap; sp.bar = c->d_bar;
+        sp.seg_max = sp.xs_bytes = sp.red_floats = sp.flags = 0;
+        sp.trace = nullptr; sp.trace_block = 0;
+        static const char *trace_env = getenv("OPUS_STACK_TRACE");     // tuning aid: workgroup id to trace
+        if (trace_env) {
+            if (!c->d_trace) { HIPC(hipMalloc(&c->d_trace, 64 * sizeof(unsigned long long))); HIPC(hipMemset(c->d_trace, 0, 64 * 8)); }
+            sp.trace = c->d_trace; sp.trace_block = atoi(trace_env);
+        }
+        // algorithmic bytes of the launch: every decoder weight once + the rows' K/V history
+        const double wbytes = 2.0 * ((double)g.dec_layers * ((double)QKV * H + (double)H * QD + 3.0 * F * H) + (double)g.dec_vocab * H);
+        const double bytes = wbytes + 4.0 * g.dec_layers * B * nkv * hd * (T + 1);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+        }
+        hipError_t e = launch_decode_stack(sp, hd, s, e0, e1);
+        if (c->timing) c->recs.push_back(TimeRec{KC_STACK, e0, e1, bytes});
+        if (e != hipSuccess) return fail(OPUS_EHIP, "decode stack launch failed: %s", hipGetErrorString(e));
+        KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
+        return OPUS_OK;
+    }
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
         OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wqkv, B, QKV, H, EPI_NONE, c->d_qkv, QKV, 0));
@@ -661,6 +726,7 @@ extern "C" int opus_llama_decode_step(opus_ctx *c, const int32_t *d_tok, float *
     int32_t st = 0;
     HIPC(hipMemcpyAsync(&st, c->d_step, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    OPC(stack_check(c));
     if (st >= c->cfg.max_new_tokens) return fail(OPUS_ESHAPE, "decode_step: KV cache is full (%d steps)", st);
     OPC(decode_step(c, s, d_tok));
     if (d_logits)
@@ -717,7 +783,8 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
     const bool use_graph = s != nullptr && !c->timing && !getenv("OPUS_NO_GRAPH");
     auto graph_matches = [&]() {
         return c->gexec && c->g_B == B && c->g_T == T && c->g_maxnew == max_new && c->g_pad == pad_id &&
-               c->g_neos == n_eos && c->g_out == d_out_ids && c->g_temp == temperature && c->g_top_p == top_p;
+               c->g_neos == n_eos && c->g_out == d_out_ids && c->g_temp == temperature && c->g_top_p == top_p &&
+               c->g_stack == stack_enabled();
     };
     const bool same_graph = graph_matches();
     std::vector<int32_t> nunf(max_new, 1);
@@ -743,7 +810,7 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
                 (void)hipGraphDestroy(graph);
                 if (ee != hipSuccess) { c->gexec = nullptr; return fail(OPUS_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ee)); }
                 c->g_B = B; c->g_T = T; c->g_maxnew = max_new; c->g_pad = pad_id; c->g_neos = n_eos;
-                c->g_temp = temperature; c->g_top_p = top_p;
+                c->g_temp = temperature; c->g_top_p = top_p; c->g_stack = stack_enabled();
                 c->g_out = d_out_ids;
             }
             HIPC(hipGraphLaunch(c->gexec, s));
@@ -761,6 +828,14 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
     }
     HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)produced * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    OPC(stack_check(c));
+    if (c->d_trace) {
+        unsigned long long tr[64];
+        HIPC(hipMemcpy(tr, c->d_trace, sizeof(tr), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[stack trace, us since first mark]");
+        for (int k = 0; k < 64 && tr[k]; ++k) fprintf(stderr, " %.2f", (double)(tr[k] - tr[0]) * 0.01);
+        fprintf(stderr, "\n");
+    }
     int n = produced;
     for (int k = 0; k < produced; ++k) if (nunf[k] == 0) { n = k + 1; break; }
     *n_out = n;
@@ -852,7 +927,7 @@ extern "C" int opus_timing_reset(opus_ctx *c) {
 }
 extern "C" int opus_timing_get(opus_ctx *c, const char *kernel_class, double *ms, int64_t *launches, double *bytes) {
     if (!c || !kernel_class || !ms || !launches || !bytes) return fail(OPUS_EBADARG, "null argument");
-    static const char *names[KC_COUNT] = {"skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other"};
+    static const char *names[KC_COUNT] = {"skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other", "decode_stack"};
     int k = -1;
     for (int i = 0; i < KC_COUNT; ++i) if (!strcmp(names[i], kernel_class)) k = i;
     if (k < 0) return fail(OPUS_EBADARG, "unknown kernel class '%s'", kernel_class);

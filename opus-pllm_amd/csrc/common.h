@@ -17,7 +17,7 @@ enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
 constexpr int SKINNY_MAX_M = 16;
 // M up to which the mid kernel (LDS-shared activations, per-wave weight stream, fused RMSNorm) is used
 constexpr int MID_MAX_M = 64;   // (65..128 rows measured faster on the split-K tile kernel)
-enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_COUNT = 5 };
+enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_STACK = 5, KC_COUNT = 6 };
 
 // C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.
 // EPI_SILU_GU16: W rows come in 32-row groups [16 gate | 16 up]; Nout = N/2, out = silu(g) * u.
@@ -103,6 +103,33 @@ hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kst
 hipError_t launch_attn_decode(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step,
                               int T0, int B, int nh, int nkv, int hd, half_t *kc, half_t *vc, int64_t cache_sb,
                               int64_t cache_sh, int ctx_cap, float scale, half_t *out, hipStream_t s);
+
+// decode_stack.hip : the whole decoder stack + lm_head of one decode step in one persistent launch (batch <= 4)
+constexpr int STACK_MAX_B = 4;
+struct StackLayer { const half_t *wqkv, *wo, *wgu, *wd; };
+struct StackParams {
+    const StackLayer *layers;   // device array [n_layers]
+    int n_layers;
+    const half_t *lm_head;
+    int B, H, F, nh, nkv, V;
+    float eps, scale;
+    float *x;                   // [B][H] fp32 residual stream (in: embedded tokens, out: last hidden state)
+    half_t *qkv, *ctx, *act;    // [B][QKV], [B][nh*hd], [B][F] scratch
+    float *logits;              // [B][V]
+    const float *cs;            // rope table
+    const int32_t *kstart, *step;
+    int T0;
+    half_t *kc, *vc;
+    int64_t cache_sl, cache_sb, cache_sh;
+    int ctx_cap;
+    unsigned *bar;              // [0] arrivals, [1] finished workgroups, [2] timeout flag, [1024 + 1024 k] go words
+                                //   (all zero between launches)
+    int seg_max, xs_bytes, red_floats, flags;   // filled by the launcher
+    unsigned long long *trace;  // tuning aid: timeline of workgroup trace_block in layer 1 (or nullptr)
+    int trace_block;
+};
+bool decode_stack_supported(int B, int H, int F, int nh, int nkv, int hd, int ctx_cap);
+hipError_t launch_decode_stack(const StackParams &p, int hd, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -299,6 +299,32 @@ def test_prefill_and_decode_logits_golden(micro, gold):
         assert torch.equal(lg.argmax(-1), ref[:, s + 1].argmax(-1))
 
 
+def test_persistent_decode_step_golden(micro, gold, monkeypatch):
+    """OPUS_STACK=1: the whole decoder stack of a decode step in one persistent launch (decode_stack.hip), same golden."""
+    cfg, model, W = micro
+    monkeypatch.setenv("OPUS_STACK", "1")
+    g = gold("generate_micro")
+    emb = torch.from_numpy(g["embeds"]).half()
+    mask = torch.from_numpy(g["mask_out"]).bool()
+    ref = torch.from_numpy(g["step_logits"])
+    free = torch.from_numpy(g["free_ids"])
+    if emb.shape[0] > 4:
+        pytest.skip("persistent kernel serves batch <= 4")
+    model.prefill_logits(emb, mask)
+    for s in range(4):
+        lg = model.decode_logits(free[:, s]).cpu()
+        assert rel_l2(lg, ref[:, s + 1]) < REL_L2, s
+        assert torch.equal(lg.argmax(-1), ref[:, s + 1].argmax(-1))
+    ids, amask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    import json as _json, os as _os
+    seqs = _json.load(open(_os.path.join(_os.path.dirname(__file__), "golden", "generate_micro.seqs.json")))
+    N = g["free_ids"].shape[1]
+    out = model.generate(ids, seqs, attention_mask=amask, pad_token_id=int(g["pad"]), do_sample=False, max_new_tokens=N)
+    assert np.array_equal(out.cpu().numpy(), g["free_ids"])
+    out2 = model.generate(ids, seqs, attention_mask=amask, pad_token_id=int(g["pad"]), do_sample=False, max_new_tokens=N)
+    assert torch.equal(out, out2)                              # graph replay of the persistent launch
+
+
 def _check_ids(got, ref, margins):
     """bit-exact up to (excluding) each row's first step with oracle margin < MARGIN_TAU."""
     got, ref = got.cpu(), ref.cpu()
