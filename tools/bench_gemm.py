@@ -91,6 +91,19 @@ if __name__ == "__main__":
         bench_tile("square 4096", 4096, 4096, 4096, 0)
         bench_tile("square 8192", 8192, 8192, 8192, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "m96":
+        for M in (96, 128, 514, 1028):
+            if M <= 128:
+                bench_tile("dec qkv", M, 6144, 4096, 0)
+                bench_tile("dec wo +res", M, 4096, 4096, 0, True, True)
+                bench_tile("dec wgu silu", M, 28672, 4096, 2)
+                bench_tile("dec wd +res", M, 4096, 14336, 0, True, True)
+            else:
+                bench_tile("esm qkv", M, 3840, 1280, 0)
+                bench_tile("esm wo +res", M, 1280, 1280, 0, True, True)
+                bench_tile("esm fc1 gelu", M, 5120, 1280, 1)
+                bench_tile("esm fc2 +res", M, 1280, 5120, 0, True, True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mid16":
         for M in (32, 64):
             bench("wgu silu (fp16 A)", M, 28672, 4096, 2, False)

@@ -3,7 +3,7 @@
 import csv, glob, sys
 d = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 14
-f = glob.glob(d + "/*/*_kernel_stats.csv")[0]
+f = (glob.glob(d + "/*_kernel_stats.csv") + glob.glob(d + "/*/*_kernel_stats.csv"))[0]
 for r in list(csv.DictReader(open(f)))[:n]:
     print(f'{r["Name"][:96]:96s} calls={r["Calls"]:>7s} total_ms={float(r["TotalDurationNs"])/1e6:9.2f} '
           f'avg_us={float(r["AverageNs"])/1e3:8.2f} pct={float(r["Percentage"]):6.2f}')
