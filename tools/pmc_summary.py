@@ -18,7 +18,7 @@ import sys
 
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
