@@ -45,9 +45,22 @@ class SyntheticTokenizer:
         self.bos_token_id = bos_token_id
         self.eos_token_id = self.pad_token_id = self.unk_token_id = eos_token_id
         self.pad_token = self.unk_token = self.eos_token = "</s>"
+        self.chat_template = None
 
-    def __call__(self, text: str):
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=False):
+        """Jinja rendering with the environment options transformers uses (trim_blocks, lstrip_blocks)."""
+        if tokenize:
+            raise NotImplementedError("SyntheticTokenizer renders chat templates to text only")
+        if self.chat_template is None:
+            raise ValueError("tokenizer.chat_template is not set")
+        from jinja2.sandbox import ImmutableSandboxedEnvironment
+        env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+        return env.from_string(self.chat_template).render(messages=messages, add_generation_prompt=add_generation_prompt)
+
+    def __call__(self, text):
         import types
+        if isinstance(text, (list, tuple)):                # a batch, as transformers tokenizers accept
+            return types.SimpleNamespace(input_ids=[self(t).input_ids for t in text])
         ids = [self.bos_token_id]
         for w in text.split():
             h = 0

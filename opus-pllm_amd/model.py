@@ -119,6 +119,10 @@ class OpusLlamaForCausalLM:
         keep = []
         for _, idxs in groups:
             toks, lens = batch_convert([seqs[i] for i in idxs])
+            if toks.shape[1] < 3:       # only empty strings: <cls><eos> + one pad column (their mean over zero residues
+                import numpy as np      # is NaN, as in the reference; such rows carry no <seq> placeholder)
+                from .alphabet import PAD_IDX
+                toks = np.concatenate([toks, np.full((toks.shape[0], 1), PAD_IDX, dtype=toks.dtype)], axis=1)
             B, T = toks.shape
             if T > cfg.max_enc_tokens:
                 raise _cabi.OpusError(-2, f"protein of {T - 2} residues exceeds max_enc_tokens={cfg.max_enc_tokens}")

@@ -127,3 +127,71 @@ def test_no_cpu_fallback():
     from opus_pllm_amd.model import OpusLlamaForCausalLM
     with pytest.raises(_cabi.OpusError):
         OpusLlamaForCausalLM(opa.micro(), None, "cpu")
+
+
+# ------------------------------------------------------------------------------------------------ N2: prompt front-ends
+def _conv_gold():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "conversation.json")))
+
+
+def test_conversation_styles_match_reference_renderings():
+    from opus_pllm_amd import conversation as cl
+    g = _conv_gold()
+    assert cl.default_chat_template == g["default_chat_template"]
+    for name, ref in g["presets"].items():
+        c = getattr(cl, name)
+        got = dict(system=c.system, roles=list(c.roles), offset=c.offset, sep_style=c.sep_style.name, sep=c.sep, sep2=c.sep2,
+                   version=c.version)
+        assert got == ref, name
+    for case in g["styles"]:
+        c = cl.Conversation(system=case["system"], roles=case["roles"], messages=[], offset=0,
+                            sep_style=getattr(cl.SeparatorStyle, case["style"]), sep=case["sep"], sep2=case["sep2"])
+        for m in case["messages"]:
+            c.append_message(m["role"], m["content"])
+        assert c.get_prompt() == case["prompt"], case["style"]
+    for style in (cl.SeparatorStyle.LLAMA_3, cl.SeparatorStyle.Qwen_2):
+        with pytest.raises(NotImplementedError):
+            cl.Conversation(system="", roles=["a", "b"], messages=[], offset=0, sep_style=style).get_prompt()
+    with pytest.raises(NotImplementedError):
+        cl.conv_vicuna_v0.copy().get_prompt_eval()                      # no tokenizer attached
+
+
+def test_chat_template_rendering_matches_transformers():
+    """The ChatML fallback through SyntheticTokenizer.apply_chat_template == the reference conversation through a
+    transformers tokenizer (golden), for both get_prompt and get_prompt_eval."""
+    from opus_pllm_amd import conversation as cl
+    from opus_pllm_amd.builder import SyntheticTokenizer
+    g = _conv_gold()["templated"][0]
+    tok = SyntheticTokenizer(512)
+    assert tok.chat_template is None
+    tok.chat_template = cl.default_chat_template
+    c = cl.conv_vicuna_v3.copy()
+    c.tokenizer = tok
+    for m in g["messages"]:
+        c.append_message(m["role"], m["content"])
+    assert c.get_prompt() == g["prompt"]
+    assert c.get_prompt_eval() == g["prompt_eval"]
+    assert tok(["a b", "c"]).input_ids == [tok("a b").input_ids, tok("c").input_ids]
+
+
+def test_multichoice_and_online_helpers():
+    from opus_pllm_amd import prompt as P
+    q = P.multichoice_prompt("Which?", ["A) x", "B) y", "C) z", "D) w"])
+    assert q.startswith("Question: Which?\n\n        Options:\n        A) x\nB) y\nC) z\nD) w\n\n        Please carefully")
+    assert q.endswith("with format 'The correct answer is' without explanation.")
+    assert P.extract_option_letter("The correct answer is b) kinase") == "B"
+    assert P.extract_option_letter("Answer: d") == "D"
+    assert P.extract_option_letter("答案是C") == "C"
+    assert P.extract_option_letter("membrane") == "membrane"            # no option: the text itself
+    recs = [dict(ground_truth="A) x", generated="The correct answer is A) x"),
+            dict(ground_truth="B", generated="C."), dict(ground_truth="D) w", generated="unsure")]
+    correct, hist = P.score_multichoice(recs)
+    assert correct == 1 and hist == {"A": 1, "B": 0, "C": 1, "D": 0, "None": 1}
+    assert P.is_protein_sequence("mkvl") and P.is_protein_sequence("") and not P.is_protein_sequence("MKVLX1")
+    p, shown = P.online_prompt("What is it?", True)
+    assert shown == "<seq>\nWhat is it?" and p.endswith("### Student: <seq>\nWhat is it?\n### Professor:")
+    p, shown = P.online_prompt("Hello", False)
+    assert "<seq>" not in p and shown == "Hello"
+    assert P.online_cut("  nucleus ### Student: next") == "nucleus"
+    assert P.online_cut("###x### y") == "###x"                         # the search starts at offset 2

@@ -153,3 +153,39 @@ def test_synthetic_preset_loader_and_batch8():
     one = model.generate(ids[3:4], seqs[3:4], attention_mask=(ids != tok.pad_token_id)[3:4], pad_token_id=tok.eos_token_id,
                          max_new_tokens=5)
     assert torch.equal(one[0], out[3])
+
+
+@pytest.mark.gpu
+def test_multichoice_and_online_drivers_run_on_synthetic_model(tmp_path, capsys):
+    """Row N2 end to end on synthetic:c1_tiny: the multiple-choice driver (chat template, empty-sequence item, option
+    scoring, JSON out) and one interactive turn with and without a protein."""
+    import argparse
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(here, "opus-pllm_amd", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    qs = [dict(question="Where is it located?", options=["A) nucleus", "B) membrane", "C) cytosol", "D) secreted"],
+               input=synth.synth_protein(40 + 9 * i, i) if i != 2 else "", answer="B) membrane") for i in range(5)]
+    inp, out = tmp_path / "q.json", tmp_path / "o.json"
+    json.dump(qs, open(inp, "w"))
+    mc = load("eval_multichoice")
+    args = argparse.Namespace(model_base_path="synthetic:c1_tiny", opus_pllm_weights_path="synthetic", input_path=str(inp),
+                              save_path=str(out), temperature=0.0, top_p=0.7, num_beams=1, max_new_tokens=6,
+                              switch_projector_type="mlp2x_gelu", load_4bit=False, load_8bit=False, batch_size=4,
+                              max_residues=128, max_prompt=256)
+    mc.eval_model(args)
+    res = json.load(open(out))
+    assert len(res) == 5 and all(r["ground_truth"] == "B) membrane" and isinstance(r["generated"], str) for r in res)
+    assert "Accuracy" in capsys.readouterr().out
+    on = load("eval_online")
+    tok, model, _ = builder.load_pretrained_model("synthetic:c1_tiny", "synthetic", "c1_tiny", device="cuda:0", max_batch=1,
+                                                  max_enc_tokens=130, max_prompt=128, max_new_tokens=8)
+    a = argparse.Namespace(temperature=0.0, top_p=0.7, num_beams=1, max_new_tokens=8)
+    shown, seq, reply = on.answer_once(model, tok, "What does it bind?", synth.synth_protein(64, 3), a)
+    assert shown.startswith("<seq>\n") and seq is not None and isinstance(reply, str)
+    shown2, seq2, reply2 = on.answer_once(model, tok, "Say hello", "", a)
+    assert shown2 == "Say hello" and seq2 is None and isinstance(reply2, str)

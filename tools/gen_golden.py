@@ -336,9 +336,49 @@ def gold_c1(cfg, w):
     save("generate_c1", ids=ids.numpy(), out_ids=out.numpy())
 
 
+
+def gold_conversation():
+    """Prompt renderings of the reference's conversation module (row N2): every separator style it renders, the
+    presets, and the ChatML fallback template through a transformers tokenizer's apply_chat_template."""
+    import dataclasses
+    from multi_modality_model.multi_modality_v1 import conversation as ref
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from transformers import PreTrainedTokenizerFast
+    out = {"default_chat_template": ref.default_chat_template, "presets": {}, "styles": [], "templated": []}
+    for name in ("conv_vicuna_v0", "conv_vicuna_v1", "conv_vicuna_v2", "conv_vicuna_v3"):
+        c = getattr(ref, name)
+        out["presets"][name] = dict(system=c.system, roles=list(c.roles), offset=c.offset, sep_style=c.sep_style.name,
+                                    sep=c.sep, sep2=c.sep2, version=c.version)
+    turns = [("hello <seq>\nWhat does it do?", "It binds ATP."), ("And where?", None)]
+    for style, sep, sep2, roles in (("SINGLE", "###", None, ["Student", "Professor"]),
+                                    ("TWO", " ", "</s>", ["USER", "ASSISTANT"]),
+                                    ("MPT", "<|im_end|>", None, ["<|im_start|>user\n", "<|im_start|>assistant\n"]),
+                                    ("LLAMA_2", "<s>", "</s>", ["USER", "ASSISTANT"]),
+                                    ("PLAIN", "\n", "\n\n", ["", ""])):
+        for system in ("You are a professor.", ""):
+            c = ref.Conversation(system=system, roles=roles, messages=[], offset=0,
+                                 sep_style=getattr(ref.SeparatorStyle, style), sep=sep, sep2=sep2)
+            for q, a in turns:
+                c.append_message(roles[0], q)
+                c.append_message(roles[1], a)
+            out["styles"].append(dict(style=style, system=system, roles=roles, sep=sep, sep2=sep2, messages=c.messages,
+                                      prompt=c.get_prompt()))
+    tok = PreTrainedTokenizerFast(tokenizer_object=Tokenizer(WordLevel({"[UNK]": 0}, unk_token="[UNK]")), unk_token="[UNK]")
+    tok.chat_template = ref.default_chat_template
+    c = ref.conv_vicuna_v3.copy()
+    c.tokenizer = tok
+    c.append_message("system", c.system)
+    c.append_message("user", "<seq>\nQuestion: which one?")
+    out["templated"].append(dict(messages=c.messages, prompt=c.get_prompt(), prompt_eval=c.get_prompt_eval()))
+    with open(os.path.join(GOLD, "conversation.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     print("tokenizer_seq_token"); gold_tokenizer()
+    print("conversation"); gold_conversation()
     cfg = opa.micro()
     w = synth.canonical_weights(cfg, seed=0)
     print("esm micro")
