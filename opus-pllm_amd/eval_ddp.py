@@ -7,6 +7,7 @@
 
 Flow (run_opus_ddp.py:47-148): load -> read JSON -> contiguous split over ranks -> batches of 8 -> prompt ->
 tokenizer_seq_token -> left-pad -> generate -> decode, cut at '###' -> gather in rank order -> rank 0 saves.
+`--use_input_embed` consumes the `.jsonl` written by `generate_esm_embedding.py`.
 Differences, all deliberate: the gather moves token ids
 (int tensor all-gather over RCCL) instead of pickled strings, task metrics (metrics_computing_opi.py) are not run.
 """
@@ -42,7 +43,11 @@ def eval_model(args):
                                                 cstp_path=cstp_path, device=f"cuda:{local}", max_batch=args.batch_size,
                                                 max_enc_tokens=args.max_residues + 2, max_prompt=args.max_prompt,
                                                 max_new_tokens=256)
-    qs = [q for q in json.load(open(args.input_path)) if q["input"] is not None]
+    if args.input_path.endswith(".jsonl"):            # stage-2 input: one item per line (generate_esm_embedding.py)
+        qs = [json.loads(line) for line in open(args.input_path) if line.strip()]
+    else:
+        qs = json.load(open(args.input_path))
+    qs = [q for q in qs if q["input"] is not None]
     n = len(qs)
     lo, hi = odist.shard_bounds(n, rank, world)
     mine = qs[lo:hi]
@@ -56,9 +61,12 @@ def eval_model(args):
         ids = [opa.tokenizer_seq_token(p, tokenizer, opa.DEFAULT_SEQ_TOKEN_INDEX, return_tensors="pt").to(dev) for p in prompts]
         ids = opa.left_pad_sequence(ids, padding_value=tokenizer.pad_token_id, batch_first=True)
         mask = ids != tokenizer.pad_token_id
+        seq_embedding = None
+        if args.use_input_embed:      # two-stage pipeline: precomputed ESM-2 embeddings (opus_arch.py:151-161)
+            seq_embedding = torch.tensor([q["input_embed"] for q in batch], dtype=torch.float32, device=dev)
         with torch.inference_mode():
             out = model.generate(ids, [q["input"] for q in batch], attention_mask=mask, pad_token_id=tokenizer.eos_token_id,
-                                 do_sample=args.temperature > 0, temperature=args.temperature, top_p=args.top_p,
+                                 seq_embedding=seq_embedding, do_sample=args.temperature > 0, temperature=args.temperature, top_p=args.top_p,
                                  num_beams=args.num_beams, max_new_tokens=max_new, use_cache=True)
         full = torch.full((out.shape[0], max_new), tokenizer.eos_token_id, dtype=torch.long, device=dev)
         full[:, : out.shape[1]] = out
@@ -92,4 +100,6 @@ if __name__ == "__main__":
     p.add_argument("--batch_size", type=int, default=8)          # hard-coded 8 in the reference (:75)
     p.add_argument("--max_residues", type=int, default=1024)
     p.add_argument("--max_prompt", type=int, default=256)
+    p.add_argument("--use_input_embed", action="store_true",
+                   help="stage 2 of the two-stage pipeline: take `input_embed` from the .jsonl instead of running ESM-2")
     eval_model(p.parse_args())

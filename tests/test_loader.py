@@ -189,3 +189,37 @@ def test_multichoice_and_online_drivers_run_on_synthetic_model(tmp_path, capsys)
     assert shown.startswith("<seq>\n") and seq is not None and isinstance(reply, str)
     shown2, seq2, reply2 = on.answer_once(model, tok, "Say hello", "", a)
     assert shown2 == "Say hello" and seq2 is None and isinstance(reply2, str)
+
+
+@pytest.mark.gpu
+def test_two_stage_pipeline_matches_one_stage(tmp_path):
+    """Row N3: generate_esm_embedding (dataset-wide, length-sorted batches, cache dict) -> .jsonl -> generate with
+    seq_embedding= gives the ids of the direct path; over-long items are dropped; cached embeddings are reused."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen", os.path.join(here, "opus-pllm_amd", "generate_esm_embedding.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    tok, model, _ = builder.load_pretrained_model("synthetic:c1_tiny", "synthetic", "c1_tiny", device="cuda:0", max_batch=4,
+                                                  max_enc_tokens=258, max_prompt=64, max_new_tokens=8)
+    seqs = [synth.synth_protein(n, i) for i, n in enumerate((33, 120, 33, 77, 200))]
+    items = [dict(instruction=f"What is protein {i}?", input=s, output="x") for i, s in enumerate(seqs)]
+    items.append(dict(instruction="too long", input="A" * 4001, output="x"))
+    cache = {seqs[3]: [0.5] * model.cfg.enc_dim}
+    out = gen.embed_dataset(model, items, cache, batch_size=4)
+    assert len(out) == 5 and all(len(o["input_embed"]) == model.cfg.enc_dim for o in out)
+    assert out[3]["input_embed"] == cache[seqs[3]]                       # cache wins
+    direct = model.encode_seq2embedding(seqs).cpu()
+    for i in (0, 1, 2, 4):
+        assert torch.equal(torch.tensor(out[i]["input_embed"]), direct[i]), i   # batch-invariant encoder
+    from opus_pllm_amd.prompt import build_prompt
+    rows = [0, 1, 4]
+    ids = [opa.tokenizer_seq_token(build_prompt(items[i]["instruction"]), tok, opa.DEFAULT_SEQ_TOKEN_INDEX, return_tensors="pt")
+           for i in rows]
+    ids = opa.left_pad_sequence(ids, padding_value=tok.pad_token_id, batch_first=True).to("cuda:0")
+    mask = ids != tok.pad_token_id
+    a = model.generate(ids, [seqs[i] for i in rows], attention_mask=mask, pad_token_id=tok.eos_token_id, max_new_tokens=8)
+    emb = torch.tensor([out[i]["input_embed"] for i in rows], dtype=torch.float32, device="cuda:0")
+    b = model.generate(ids, [seqs[i] for i in rows], attention_mask=mask, pad_token_id=tok.eos_token_id, max_new_tokens=8,
+                       seq_embedding=emb)
+    assert torch.equal(a, b)
