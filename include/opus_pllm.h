@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 1
+#define OPUS_ABI_VERSION 2
 
 enum opus_status {
     OPUS_OK = 0,
@@ -52,6 +52,10 @@ typedef struct opus_config {
     int32_t dec_layers, dec_dim, dec_heads, dec_kv_heads, dec_head_dim, dec_ffn, dec_vocab;
     float dec_rms_eps, dec_rope_theta;
     int32_t max_batch, max_enc_tokens, max_prompt, max_new_tokens;
+    /* decoder family (model/builder.py:60-92): dec_arch 0 = Llama / Qwen2 (dec_qkv_bias: q/k/v biases),
+     * 1 = OPT / Galactica with do_layer_norm_before (learned positions [dec_max_pos + 2, dim], LayerNorm, biased
+     * projections, fc1 - GELU - fc2; dec_act must be 0 = GELU; dec_rms_eps is then the LayerNorm epsilon) */
+    int32_t dec_arch, dec_qkv_bias, dec_act, dec_max_pos;
 } opus_config;
 
 typedef struct opus_ctx opus_ctx;

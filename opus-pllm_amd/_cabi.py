@@ -13,7 +13,7 @@ from .config import OpusConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libopus_pllm.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OPUS_F16, OPUS_F32, OPUS_I32, OPUS_I64, OPUS_U8 = 0, 1, 2, 3, 4
 
@@ -36,6 +36,7 @@ class CConfig(C.Structure):
         ("dec_rms_eps", C.c_float), ("dec_rope_theta", C.c_float),
         ("max_batch", C.c_int32), ("max_enc_tokens", C.c_int32), ("max_prompt", C.c_int32),
         ("max_new_tokens", C.c_int32),
+        ("dec_arch", C.c_int32), ("dec_qkv_bias", C.c_int32), ("dec_act", C.c_int32), ("dec_max_pos", C.c_int32),
     ]
 
     @classmethod

@@ -89,9 +89,37 @@ def _load_safetensors_dir(path: str) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def _load_torch_bin_dir(path: str) -> Dict[str, torch.Tensor]:
+    """pytorch_model*.bin shards (the reference loads OPT / Galactica bases with use_safetensors=False, builder.py:72-76);
+    safetensors are accepted too when that is what the directory holds."""
+    files = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+    if not files:
+        return _load_safetensors_dir(path)
+    sd: Dict[str, torch.Tensor] = {}
+    for f in files:
+        sd.update(torch.load(f, map_location="cpu", weights_only=True))
+    return sd
+
+
 def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, switch_depth: int = 2, **cap) -> OpusConfig:
-    """HF Llama config.json + the reference's hard-coded protein dims -> OpusConfig."""
+    """HF config.json (Llama, Qwen2 or OPT / Galactica) + the reference's hard-coded protein dims -> OpusConfig."""
     H, nh = hf_cfg["hidden_size"], hf_cfg["num_attention_heads"]
+    if hf_cfg.get("model_type") == "opt":
+        if not hf_cfg.get("do_layer_norm_before", True):
+            raise NotImplementedError("post-LayerNorm OPT (opt-350m) is not built")
+        if hf_cfg.get("word_embed_proj_dim", H) != H:
+            raise NotImplementedError("OPT with project_in / project_out (word_embed_proj_dim != hidden_size) is not built")
+        if hf_cfg.get("activation_function", "relu") != "gelu":
+            raise NotImplementedError("only the GELU OPT variants (Galactica) are built")
+        return OpusConfig(**esm2_dims(esm), proj_dim=proj_dim, switch_depth=switch_depth, dec_arch=1,
+                          dec_layers=hf_cfg["num_hidden_layers"], dec_dim=H, dec_heads=nh, dec_kv_heads=nh,
+                          dec_head_dim=H // nh, dec_ffn=hf_cfg["ffn_dim"], dec_vocab=hf_cfg["vocab_size"], dec_rms_eps=1e-5,
+                          dec_max_pos=hf_cfg.get("max_position_embeddings", 2048), **cap).validate()
+    qkv_bias = 1 if hf_cfg.get("model_type") == "qwen2" or hf_cfg.get("attention_bias") else 0
+    if hf_cfg.get("attention_bias") and hf_cfg.get("model_type") != "qwen2":
+        raise NotImplementedError("Llama attention_bias (bias on o_proj as well) is not built")
+    if hf_cfg.get("use_sliding_window"):
+        raise NotImplementedError("sliding-window attention is not built")
     rope = hf_cfg.get("rope_theta") or (hf_cfg.get("rope_parameters") or {}).get("rope_theta", 10000.0)
     if hf_cfg.get("rope_scaling"):
         raise NotImplementedError("rope_scaling is not built (Llama-3-8B and Vicuna use plain rotary)")
@@ -99,7 +127,8 @@ def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, sw
                       dec_layers=hf_cfg["num_hidden_layers"], dec_dim=H, dec_heads=nh,
                       dec_kv_heads=hf_cfg.get("num_key_value_heads", nh), dec_head_dim=hf_cfg.get("head_dim") or H // nh,
                       dec_ffn=hf_cfg["intermediate_size"], dec_vocab=hf_cfg["vocab_size"],
-                      dec_rms_eps=hf_cfg.get("rms_norm_eps", 1e-5), dec_rope_theta=float(rope), **cap).validate()
+                      dec_rms_eps=hf_cfg.get("rms_norm_eps", 1e-5), dec_rope_theta=float(rope), dec_qkv_bias=qkv_bias,
+                      **cap).validate()
 
 
 def canonical_from_hf_llama(sd: Dict[str, torch.Tensor], cfg: OpusConfig) -> Dict[str, torch.Tensor]:
@@ -111,8 +140,35 @@ def canonical_from_hf_llama(sd: Dict[str, torch.Tensor], cfg: OpusConfig) -> Dic
         out[d + "post_norm.weight"] = sd[s + "post_attention_layernorm.weight"]
         for a in ("q", "k", "v", "o"):
             out[d + a + ".weight"] = sd[s + f"self_attn.{a}_proj.weight"]
+        if cfg.dec_qkv_bias:                                   # Qwen2
+            for a in ("q", "k", "v"):
+                out[d + a + ".bias"] = sd[s + f"self_attn.{a}_proj.bias"]
         for a in ("gate", "up", "down"):
             out[d + a + ".weight"] = sd[s + f"mlp.{a}_proj.weight"]
+    return out
+
+
+def canonical_from_hf_opt(sd: Dict[str, torch.Tensor], cfg: OpusConfig) -> Dict[str, torch.Tensor]:
+    """transformers OPTForCausalLM state dict ('model.decoder.' / 'decoder.' prefixes).  Absent biases
+    (`enable_bias=False`) become zeros, absent LayerNorm parameters (`layer_norm_elementwise_affine=False`) ones / zeros,
+    an absent lm_head is the tied embedding table."""
+    pre = next(p for p in ("model.decoder.", "decoder.", "") if p + "embed_tokens.weight" in sd)
+    H = cfg.dec_dim
+
+    def get(k, shape, fill):
+        return sd[pre + k] if pre + k in sd else torch.full(shape, fill, dtype=torch.float32)
+    out = {"dec.embed_tokens": sd[pre + "embed_tokens.weight"], "dec.embed_positions": sd[pre + "embed_positions.weight"],
+           "dec.norm.weight": get("final_layer_norm.weight", (H,), 1.0), "dec.norm.bias": get("final_layer_norm.bias", (H,), 0.0),
+           "dec.lm_head.weight": sd.get("lm_head.weight", sd[pre + "embed_tokens.weight"])}
+    names = (("ln1", "self_attn_layer_norm", H), ("q", "self_attn.q_proj", cfg.dec_q_dim), ("k", "self_attn.k_proj", cfg.dec_kv_dim),
+             ("v", "self_attn.v_proj", cfg.dec_kv_dim), ("o", "self_attn.out_proj", H), ("ln2", "final_layer_norm", H),
+             ("fc1", "fc1", cfg.dec_ffn), ("fc2", "fc2", H))
+    for l in range(cfg.dec_layers):
+        d = f"dec.layers.{l}."
+        for a, b_, rows in names:
+            k = f"layers.{l}.{b_}."
+            out[d + a + ".weight"] = get(k + "weight", (rows,), 1.0) if a.startswith("ln") else sd[pre + k + "weight"]
+            out[d + a + ".bias"] = get(k + "bias", (rows,), 0.0)
     return out
 
 
@@ -160,7 +216,8 @@ def lora_from_peft(adapter_dir: str, cfg: OpusConfig) -> Dict[str, Tuple[torch.T
         sd = load_file(st)
     else:
         sd = torch.load(os.path.join(adapter_dir, "adapter_model.bin"), map_location="cpu", weights_only=True)
-    names = {"q_proj": "q", "k_proj": "k", "v_proj": "v", "o_proj": "o", "gate_proj": "gate", "up_proj": "up", "down_proj": "down"}
+    names = {"q_proj": "q", "k_proj": "k", "v_proj": "v", "o_proj": "o", "gate_proj": "gate", "up_proj": "up", "down_proj": "down",
+             "out_proj": "o", "fc1": "fc1", "fc2": "fc2"}                     # the last three: OPT / Galactica module names
     out = {}
     for k, A in sd.items():
         if "lora_A" not in k:
@@ -208,18 +265,31 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
                                      pad_token_id=tokenizer.pad_token_id)
         return tokenizer, model, 512
 
+    # family by substring of the base path, in the reference's order (builder.py:60-96)
     low = model_base_path.lower()
-    if "llama" not in low and "vicuna" not in low:
-        # the reference also dispatches on 'opt'/'galactica'/'qwen' (builder.py:71-96): other decoder families
-        raise NotImplementedError("only the Llama decoder family is built (SURVEY 8f N4)")
+    if "llama" in low or "vicuna" in low:
+        family = "llama"
+    elif "opt" in low or "galactica" in low:
+        family = "opt"
+    elif "qwen" in low:
+        family = "qwen"
+    else:
+        raise NotImplementedError
     with open(os.path.join(model_base_path, "config.json")) as f:
         hf_cfg = json.load(f)
     cfg = config_from_hf(hf_cfg, switch_depth=depth, **cap)
-    canon = canonical_from_hf_llama(_load_safetensors_dir(model_base_path), cfg)
+    if (family == "opt") != (cfg.dec_arch == 1):
+        raise ValueError(f"{model_base_path}: path says '{family}' but config.json model_type is {hf_cfg.get('model_type')!r}")
     import transformers
     tokenizer = transformers.AutoTokenizer.from_pretrained(model_base_path, use_fast=False)
-    tokenizer.pad_token = tokenizer.unk_token = tokenizer.eos_token
-    tokenizer.pad_token_id = tokenizer.unk_token_id = tokenizer.eos_token_id
+    if family == "opt":
+        canon = canonical_from_hf_opt(_load_torch_bin_dir(model_base_path), cfg)
+        tokenizer.pad_token, tokenizer.unk_token, tokenizer.eos_token = "<pad>", "<unk>", "</s>"      # builder.py:78-80
+    else:
+        canon = canonical_from_hf_llama(_load_safetensors_dir(model_base_path), cfg)
+        if family == "llama":
+            tokenizer.pad_token = tokenizer.unk_token = tokenizer.eos_token
+            tokenizer.pad_token_id = tokenizer.unk_token_id = tokenizer.eos_token_id
     if accelerator is not None:
         accelerator.wait_for_everyone()
     lora = None

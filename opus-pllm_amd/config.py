@@ -42,6 +42,12 @@ class OpusConfig:
     max_enc_tokens: int = 1026         # L_max + 2 (<cls>, <eos>)
     max_prompt: int = 128              # decoder positions after the splice
     max_new_tokens: int = 256
+    # --- decoder family (model/builder.py:60-92) ---
+    dec_arch: int = 0                  # 0: Llama / Qwen2 (RMSNorm, rotary, SwiGLU); 1: OPT / Galactica (pre-LayerNorm,
+    #                                    learned positions with offset 2, fc1-act-fc2, biases; `do_layer_norm_before`)
+    dec_qkv_bias: int = 0              # arch 0: q/k/v projections carry a bias (Qwen2)
+    dec_act: int = 0                   # arch 1: 0 = erf-GELU (Galactica); ReLU OPTs are not built
+    dec_max_pos: int = 2048            # arch 1: rows of the learned position table (+2 offset rows)
 
     # ---- derived ----
     @property
@@ -82,6 +88,11 @@ class OpusConfig:
         req(self.dec_ffn % 16 == 0, "dec_ffn must be a multiple of 16 (gate/up interleave)")
         req(self.switch_depth >= 1, "switch_depth >= 1")
         req(self.n_prot_tokens >= 1, "n_prot_tokens >= 1")
+        req(self.dec_arch in (0, 1), "dec_arch: 0 (Llama/Qwen2) or 1 (OPT/Galactica)")
+        if self.dec_arch == 1:
+            req(self.dec_heads == self.dec_kv_heads, "OPT attention is multi-head (dec_kv_heads == dec_heads)")
+            req(self.dec_act == 0, "only the GELU OPT variants (Galactica) are built")
+            req(self.max_prompt + self.max_new_tokens <= self.dec_max_pos, "context exceeds the learned position table")
         return self
 
     def with_capacity(self, **kw) -> "OpusConfig":
@@ -142,4 +153,37 @@ def micro(**kw) -> OpusConfig:
     return OpusConfig(**{**base, **kw}).validate()
 
 
-PRESETS = {"llama3_8b": llama3_8b, "vicuna_13b": vicuna_13b, "c1_tiny": c1_tiny, "micro": micro}
+def galactica_1_3b(**kw) -> OpusConfig:
+    """OPUS-PLLM-Galactica-1.3B shape (README model zoo): ESM2-650M + OPT-architecture decoder, 24 x 2048, 32 heads."""
+    base = dict(dec_arch=1, dec_layers=24, dec_dim=2048, dec_heads=32, dec_kv_heads=32, dec_head_dim=64, dec_ffn=8192,
+                dec_vocab=50000, dec_rms_eps=1e-5, dec_max_pos=2048)
+    return OpusConfig(**{**esm2_dims("t33_650M"), **base, **kw}).validate()
+
+
+def galactica_6_7b(**kw) -> OpusConfig:
+    """OPUS-PLLM-Galactica-6.7B shape: 32 x 4096, 32 heads of 128."""
+    base = dict(dec_arch=1, dec_layers=32, dec_dim=4096, dec_heads=32, dec_kv_heads=32, dec_head_dim=128, dec_ffn=16384,
+                dec_vocab=50000, dec_rms_eps=1e-5, dec_max_pos=2048)
+    return OpusConfig(**{**esm2_dims("t33_650M"), **base, **kw}).validate()
+
+
+def qwen2_7b(**kw) -> OpusConfig:
+    """Qwen2.5-7B decoder shape (model/builder.py:83-92 loads Qwen bases): Llama block + q/k/v biases."""
+    base = dict(dec_qkv_bias=1, dec_layers=28, dec_dim=3584, dec_heads=28, dec_kv_heads=4, dec_head_dim=128, dec_ffn=18944,
+                dec_vocab=152064, dec_rms_eps=1e-6, dec_rope_theta=1000000.0)
+    return OpusConfig(**{**esm2_dims("t33_650M"), **base, **kw}).validate()
+
+
+def micro_opt(**kw) -> OpusConfig:
+    """micro with the OPT-architecture decoder (golden fixtures of row N4)."""
+    return micro(dec_arch=1, dec_kv_heads=4, dec_max_pos=96, **kw)
+
+
+def micro_qwen(**kw) -> OpusConfig:
+    """micro with q/k/v biases (golden fixtures of row N4)."""
+    return micro(dec_qkv_bias=1, **kw)
+
+
+PRESETS = {"llama3_8b": llama3_8b, "vicuna_13b": vicuna_13b, "c1_tiny": c1_tiny, "micro": micro,
+           "galactica_1_3b": galactica_1_3b, "galactica_6_7b": galactica_6_7b, "qwen2_7b": qwen2_7b,
+           "micro_opt": micro_opt, "micro_qwen": micro_qwen}

@@ -46,8 +46,12 @@ struct EncLayer {
     const float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2;
     const half_t *wqkv, *wo, *w1, *w2;
 };
-struct DecLayer {   // RMSNorm weights are folded into wqkv / wgu (and dec.lnf into lm_head) at load time
-    const half_t *wqkv, *wo, *wgu, *wd;
+struct DecLayer {   // arch 0: RMSNorm weights are folded into wqkv / wgu (and dec.lnf into lm_head) at load time
+    const half_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
+    const float *bqkv = nullptr;                      // Qwen2 q/k/v bias, OPT bias
+    // arch 1 (OPT / Galactica): LayerNorm affine parameters, fc1 / fc2 and the remaining biases
+    const half_t *w1 = nullptr, *w2 = nullptr;
+    const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
 };
 
 struct TimeRec {
@@ -62,8 +66,8 @@ struct opus_ctx {
     std::map<std::string, Tensor> w;
     bool resolved = false;
     // resolved weights
-    const half_t *enc_emb = nullptr, *dec_emb = nullptr, *lm_head = nullptr, *proj_w = nullptr;
-    const float *enc_lnfw = nullptr, *enc_lnfb = nullptr, *proj_b = nullptr;
+    const half_t *enc_emb = nullptr, *dec_emb = nullptr, *lm_head = nullptr, *proj_w = nullptr, *dec_pos = nullptr;
+    const float *enc_lnfw = nullptr, *enc_lnfb = nullptr, *proj_b = nullptr, *dec_lnfw = nullptr, *dec_lnfb = nullptr;
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;
     std::vector<const half_t *> sw_w;
@@ -192,6 +196,13 @@ static int check_cfg(const opus_config *g) {
     if (g->switch_depth < 1 || g->n_prot_tokens < 1) return fail(OPUS_EBADARG, "switch_depth/n_prot_tokens");
     if (g->max_batch < 1 || g->max_enc_tokens < 3 || g->max_prompt < 1 || g->max_new_tokens < 1)
         return fail(OPUS_EBADARG, "capacity fields must be positive");
+    if (g->dec_arch != 0 && g->dec_arch != 1) return fail(OPUS_EBADARG, "dec_arch must be 0 (Llama/Qwen2) or 1 (OPT/Galactica)");
+    if (g->dec_arch == 1) {
+        if (g->dec_heads != g->dec_kv_heads) return fail(OPUS_ESHAPE, "OPT attention is multi-head: dec_kv_heads == dec_heads");
+        if (g->dec_act != 0) return fail(OPUS_EUNSUPPORTED, "only the GELU OPT variants (Galactica) are built");
+        if (g->max_prompt + g->max_new_tokens > g->dec_max_pos)
+            return fail(OPUS_ESHAPE, "max_prompt + max_new_tokens exceeds the learned position table (dec_max_pos=%d)", g->dec_max_pos);
+    }
     return OPUS_OK;
 }
 
@@ -242,6 +253,8 @@ extern "C" int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **ou
     fill_cs(t, cfg->max_enc_tokens, cfg->enc_dim / cfg->enc_heads, cfg->enc_rope_theta);
     HIPC(hipMemcpy(c->cs_enc, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     fill_cs(t, cfg->max_prompt + cfg->max_new_tokens, cfg->dec_head_dim, cfg->dec_rope_theta);
+    if (cfg->dec_arch == 1)      // no rotary in OPT: (cos, sin) = (1, 0) makes the fused rotate-and-cache kernels plain copies
+        for (size_t i = 0; i < t.size(); i += 2) { t[i] = 1.0f; t[i + 1] = 0.0f; }
     HIPC(hipMemcpy(c->cs_dec, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPC(hipMemset(c->d_step, 0, 16));
     *out = c;
@@ -348,13 +361,32 @@ extern "C" int opus_weights_ready(opus_ctx *c) {
         DecLayer &L = c->dec[l];
         GW(p + "wqkv", OPUS_F16, (std::vector<int64_t>{QKV, H}), L.wqkv);
         GW(p + "wo", OPUS_F16, (std::vector<int64_t>{H, QD}), L.wo);
+        if (g.dec_arch == 1) {
+            GW(p + "ln1.w", OPUS_F32, (std::vector<int64_t>{H}), L.ln1w);
+            GW(p + "ln1.b", OPUS_F32, (std::vector<int64_t>{H}), L.ln1b);
+            GW(p + "bqkv", OPUS_F32, (std::vector<int64_t>{QKV}), L.bqkv);
+            GW(p + "bo", OPUS_F32, (std::vector<int64_t>{H}), L.bo);
+            GW(p + "ln2.w", OPUS_F32, (std::vector<int64_t>{H}), L.ln2w);
+            GW(p + "ln2.b", OPUS_F32, (std::vector<int64_t>{H}), L.ln2b);
+            GW(p + "w1", OPUS_F16, (std::vector<int64_t>{F, H}), L.w1);
+            GW(p + "b1", OPUS_F32, (std::vector<int64_t>{F}), L.b1);
+            GW(p + "w2", OPUS_F16, (std::vector<int64_t>{H, F}), L.w2);
+            GW(p + "b2", OPUS_F32, (std::vector<int64_t>{H}), L.b2);
+            continue;
+        }
+        if (g.dec_qkv_bias) GW(p + "bqkv", OPUS_F32, (std::vector<int64_t>{QKV}), L.bqkv);
         GW(p + "wgu", OPUS_F16, (std::vector<int64_t>{2 * F, H}), L.wgu);
         GW(p + "wd", OPUS_F16, (std::vector<int64_t>{H, F}), L.wd);
+    }
+    if (g.dec_arch == 1) {
+        GW("dec.pos", OPUS_F16, (std::vector<int64_t>{g.dec_max_pos + 2, H}), c->dec_pos);
+        GW("dec.lnf.w", OPUS_F32, (std::vector<int64_t>{H}), c->dec_lnfw);
+        GW("dec.lnf.b", OPUS_F32, (std::vector<int64_t>{H}), c->dec_lnfb);
     }
     GW("dec.lm_head", OPUS_F16, (std::vector<int64_t>{V, H}), c->lm_head);
     {
         std::vector<StackLayer> tab(g.dec_layers);
-        for (int l = 0; l < g.dec_layers; ++l) tab[l] = StackLayer{c->dec[l].wqkv, c->dec[l].wo, c->dec[l].wgu, c->dec[l].wd};
+        for (int l = 0; l < g.dec_layers; ++l) tab[l] = StackLayer{c->dec[l].wqkv, c->dec[l].wo, c->dec[l].wgu, c->dec[l].wd};   // (arch 0)
         if (!c->d_stack_layers) HIPC(hipMalloc(&c->d_stack_layers, tab.size() * sizeof(StackLayer)));
         HIPC(hipMemcpy(c->d_stack_layers, tab.data(), tab.size() * sizeof(StackLayer), hipMemcpyHostToDevice));
         const size_t bar_words = 1024 + 16 * 1024;                 // counters + 16 "go" words 4 KB apart
@@ -427,15 +459,15 @@ static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const 
 // C = epi(rmsnorm(X) W'^T) with the norm weight pre-folded into W': fused in the skinny kernel (M <= 64),
 // otherwise a weight-less rmsnorm kernel into `scratch` followed by the tile kernel.
 static int gemm_norm(opus_ctx *c, hipStream_t s, const float *X, float eps, half_t *scratch, const half_t *W, int M, int N,
-                     int K, int epi, void *C, int64_t ldc, int out_f32) {
+                     int K, int epi, void *C, int64_t ldc, int out_f32, const float *bias = nullptr) {
     static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;
     static const bool mid_v1 = getenv("OPUS_MID_V1") != nullptr;
     // 17..64 rows with a wide output (wgu, lm_head): the wide kernel wants fp16 activations, so norm separately
     const bool wide = M > SKINNY_MAX_M && N >= 16384 && !mid_v1;
     if (M <= SKINNY_MAX_M || (M <= MID_MAX_M && !no_mid && !wide))
-        return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
+        return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, bias, epi, nullptr, C, ldc, out_f32);
     KL(KC_OTHER, 6.0 * M * K, launch_rmsnorm(X, nullptr, eps, M, K, scratch, s));
-    return gemm(c, s, scratch, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
+    return gemm(c, s, scratch, K, W, M, N, K, bias, epi, nullptr, C, ldc, out_f32);
 }
 
 static int need_ready(opus_ctx *c) {
@@ -591,7 +623,80 @@ static int lm_head(opus_ctx *c, hipStream_t s, int B) {
                      g.dec_vocab, 1);
 }
 
+
+// ------------------------------------------------------------------------------------------------ OPT / Galactica decoder
+// transformers OPTDecoder with do_layer_norm_before (reference wrapper language_model/opus_opt.py:18-40):
+//   x = inputs_embeds + pos;  per layer  x += Wo attn(LN1 x) + bo;  x += W2 gelu(W1 LN2 x + b1) + b2;  logits = lm_head LNf x.
+// No rotary: the (cos, sin) table holds (1, 0), so the fused rotate-and-cache kernels only append to the KV cache; the
+// query scale head_dim^-0.5 is applied to the scores in fp32.
+static int opt_layer(opus_ctx *c, hipStream_t s, const DecLayer &L, int l, float *x, half_t *xn, int M, int B, int T, bool decode) {
+    const opus_config &g = c->cfg;
+    const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
+    const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
+    KL(KC_OTHER, 6.0 * M * H, launch_layernorm(x, L.ln1w, L.ln1b, g.dec_rms_eps, M, H, xn, nullptr, s));
+    OPC(gemm(c, s, xn, H, L.wqkv, M, QKV, H, L.bqkv, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
+    if (decode) {
+        KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (T + 1),
+           launch_attn_decode(c->d_qkv, c->cs_dec, c->d_kstart, c->d_step, T, B, nh, nkv, hd, c->kc + l * c->cache_sl,
+                              c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, g.max_prompt + g.max_new_tokens,
+                              1.0f / sqrtf((float)hd), c->d_ctx, s));
+    } else {
+        KL(KC_OTHER, 4.0 * M * QKV,
+           launch_dec_rope_cache(c->d_qkv, c->cs_dec, c->d_kstart, B, T, nh, nkv, hd, c->kc + l * c->cache_sl,
+                                 c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, s));
+        AttnParams a;
+        a.Q = c->d_qkv; a.K = c->d_qkv + QD; a.V = c->d_qkv + QD + nkv * hd;
+        a.q_sb = a.k_sb = a.v_sb = (int64_t)T * QKV;
+        a.q_st = a.k_st = a.v_st = QKV;
+        a.O = c->d_ctx; a.o_sb = (int64_t)T * QD; a.o_st = QD;
+        a.kstart = c->d_kstart; a.kend = nullptr;
+        a.B = B; a.T = T; a.heads = nh; a.group = nh / nkv; a.head_dim = hd; a.causal = 1;
+        a.scale = 1.0f / sqrtf((float)hd);
+        KL(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), launch_attn_prefill(a, s));
+    }
+    OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, L.bo, EPI_NONE, x, x, H, 1));
+    KL(KC_OTHER, 6.0 * M * H, launch_layernorm(x, L.ln2w, L.ln2b, g.dec_rms_eps, M, H, xn, nullptr, s));
+    OPC(gemm(c, s, xn, H, L.w1, M, F, H, L.b1, EPI_GELU, nullptr, c->d_act, F, 0));
+    OPC(gemm(c, s, c->d_act, F, L.w2, M, H, F, L.b2, EPI_NONE, x, x, H, 1));
+    return OPUS_OK;
+}
+
+static int lm_head_opt(opus_ctx *c, hipStream_t s, int B) {
+    const opus_config &g = c->cfg;
+    KL(KC_OTHER, 6.0 * B * g.dec_dim, launch_layernorm(c->d_xl, c->dec_lnfw, c->dec_lnfb, g.dec_rms_eps, B, g.dec_dim, c->d_xln, nullptr, s));
+    return gemm(c, s, c->d_xln, g.dec_dim, c->lm_head, B, g.dec_vocab, g.dec_dim, nullptr, EPI_NONE, nullptr, c->d_logits,
+                g.dec_vocab, 1);
+}
+
+static int prefill_opt(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8_t *mask, int B, int T) {
+    const opus_config &g = c->cfg;
+    const int H = g.dec_dim, M = B * T;
+    KL(KC_OTHER, 1.0 * M, launch_mask_to_kstart(mask, B, T, c->d_kstart, s));
+    KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
+    KL(KC_OTHER, 10.0 * M * H, launch_add_pos(c->d_x, c->dec_pos, c->d_kstart, nullptr, 0, B, T, H, g.dec_max_pos + 1, s));
+    for (int l = 0; l < g.dec_layers; ++l) OPC(opt_layer(c, s, c->dec[l], l, c->d_x, c->d_xn, M, B, T, false));
+    KL(KC_OTHER, 8.0 * B * H, launch_take_last(c->d_x, B, T, H, c->d_xl, s));
+    OPC(lm_head_opt(c, s, B));
+    HIPC(hipMemsetAsync(c->d_step, 0, sizeof(int32_t), s));
+    c->cur_B = B;
+    c->cur_T = T;
+    c->prefilled = true;
+    return OPUS_OK;
+}
+
+// the embedded new tokens are already in d_xl (decode_step)
+static int decode_step_opt(opus_ctx *c, hipStream_t s) {
+    const opus_config &g = c->cfg;
+    const int B = c->cur_B, T = c->cur_T, H = g.dec_dim;
+    KL(KC_OTHER, 10.0 * B * H, launch_add_pos(c->d_xl, c->dec_pos, c->d_kstart, c->d_step, T, B, 1, H, g.dec_max_pos + 1, s));
+    for (int l = 0; l < g.dec_layers; ++l) OPC(opt_layer(c, s, c->dec[l], l, c->d_xl, c->d_xln, B, B, T, true));
+    OPC(lm_head_opt(c, s, B));
+    KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
+    return OPUS_OK;
+}
+
 static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8_t *mask, int B, int T) {
+    if (c->cfg.dec_arch == 1) return prefill_opt(c, s, embeds, mask, B, T);
     const opus_config &g = c->cfg;
     const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
     const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
@@ -600,7 +705,7 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
     KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
-        OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wqkv, M, QKV, H, EPI_NONE, c->d_qkv, QKV, 0));
+        OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wqkv, M, QKV, H, EPI_NONE, c->d_qkv, QKV, 0, L.bqkv));
         KL(KC_OTHER, 4.0 * M * QKV,
            launch_dec_rope_cache(c->d_qkv, c->cs_dec, c->d_kstart, B, T, nh, nkv, hd, c->kc + l * c->cache_sl,
                                  c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, s));
@@ -653,7 +758,8 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
     const int ctx_cap = g.max_prompt + g.max_new_tokens;
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, s));
-    if (stack_enabled() && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap)) {
+    if (g.dec_arch == 1) return decode_step_opt(c, s);
+    if (stack_enabled() && !g.dec_qkv_bias && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap)) {
         c->stack_used = true;
         StackParams sp;
         sp.layers = c->d_stack_layers; sp.n_layers = g.dec_layers; sp.lm_head = c->lm_head;
@@ -686,7 +792,7 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     }
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
-        OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wqkv, B, QKV, H, EPI_NONE, c->d_qkv, QKV, 0));
+        OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wqkv, B, QKV, H, EPI_NONE, c->d_qkv, QKV, 0, L.bqkv));
         KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (T + 1),
            launch_attn_decode(c->d_qkv, c->cs_dec, c->d_kstart, c->d_step, T, B, nh, nkv, hd, c->kc + l * c->cache_sl,
                               c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, ctx_cap, 1.0f / sqrtf((float)hd),

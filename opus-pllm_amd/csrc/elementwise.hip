@@ -147,6 +147,33 @@ hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// OPT / Galactica learned positions (transformers OPTLearnedPositionalEmbedding): x[b, tq, :] += pos[idx, :] with
+// idx = cumsum(mask) * mask - 1 + 2, which for a left-padded row is (slot - kstart[b]) + 2 on real slots and 1 on pads.
+// slot = t0 (+ *step when step != nullptr: the decode step reads it from the device so that a graph can replay) + tq.
+__global__ __launch_bounds__(256) void add_pos_kernel(float *__restrict__ x, const half_t *__restrict__ pos,
+                                                      const int32_t *__restrict__ kstart, const int32_t *__restrict__ step,
+                                                      int t0, int Tq, int H, int max_idx) {
+    const int row = blockIdx.x, b = row / Tq, tq = row % Tq;
+    const int slot = t0 + (step ? *step : 0) + tq;
+    int idx = slot >= kstart[b] ? slot - kstart[b] + 2 : 1;
+    idx = idx > max_idx ? max_idx : idx;
+    for (int c = threadIdx.x; c < (H >> 3); c += 256) {
+        const h8 e = *reinterpret_cast<const h8 *>(pos + (int64_t)idx * H + c * 8);
+        float4 *o = reinterpret_cast<float4 *>(x + (int64_t)row * H + c * 8);
+        float4 a = o[0], d = o[1];
+        a.x += (float)e[0]; a.y += (float)e[1]; a.z += (float)e[2]; a.w += (float)e[3];
+        d.x += (float)e[4]; d.y += (float)e[5]; d.z += (float)e[6]; d.w += (float)e[7];
+        o[0] = a;
+        o[1] = d;
+    }
+}
+hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, const int32_t *step, int t0, int B, int Tq,
+                          int H, int max_idx, hipStream_t s) {
+    if (H & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_pos_kernel, dim3(B * Tq), dim3(256), 0, s, x, pos, kstart, step, t0, Tq, H, max_idx);
+    return hipGetLastError();
+}
+
 // x[b,:] = fp32(emb[tok[b]]) : embedding of the token just generated (input of the next decode step)
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__restrict__ tok, const half_t *__restrict__ emb,
                                                            int H, int V, float *__restrict__ x) {

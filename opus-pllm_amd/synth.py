@@ -110,12 +110,27 @@ def canonical_spec(cfg: OpusConfig) -> List[Tuple[str, Tuple[int, ...], float, f
         d_in = cfg.switch_out
     out.append(("dec.embed_tokens", (V, H), 1.0, 0.0))
     g_dec = 1.0 / math.sqrt(2.0 * cfg.dec_layers)
+    if cfg.dec_arch == 1:       # OPT / Galactica: learned positions, pre-LayerNorm, biased projections, fc1-act-fc2
+        out.append(("dec.embed_positions", (cfg.dec_max_pos + 2, H), 0.5, 0.0))
+        for l in range(cfg.dec_layers):
+            p = f"dec.layers.{l}."
+            ln(p + "ln1", H)
+            lin(p + "q", cfg.dec_q_dim, H, 2.0)
+            lin(p + "k", cfg.dec_kv_dim, H, 2.0)
+            lin(p + "v", cfg.dec_kv_dim, H)
+            lin(p + "o", H, cfg.dec_q_dim, g_dec)
+            ln(p + "ln2", H)
+            lin(p + "fc1", F, H)
+            lin(p + "fc2", H, F, g_dec)
+        ln("dec.norm", H)
+        lin("dec.lm_head", V, H, 4.0, bias=False)
+        return out
     for l in range(cfg.dec_layers):
         p = f"dec.layers.{l}."
         ln(p + "input_norm", H, bias=False)
-        lin(p + "q", cfg.dec_q_dim, H, 2.0, bias=False)
-        lin(p + "k", cfg.dec_kv_dim, H, 2.0, bias=False)
-        lin(p + "v", cfg.dec_kv_dim, H, bias=False)
+        lin(p + "q", cfg.dec_q_dim, H, 2.0, bias=bool(cfg.dec_qkv_bias))
+        lin(p + "k", cfg.dec_kv_dim, H, 2.0, bias=bool(cfg.dec_qkv_bias))
+        lin(p + "v", cfg.dec_kv_dim, H, bias=bool(cfg.dec_qkv_bias))
         lin(p + "o", H, cfg.dec_q_dim, g_dec, bias=False)
         ln(p + "post_norm", H, bias=False)
         lin(p + "gate", F, H, bias=False)

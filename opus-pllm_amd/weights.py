@@ -87,10 +87,29 @@ def fused_spec(cfg: OpusConfig) -> List[Fused]:
         mat(f"sw.{i}.w", f"switch.{i}.weight", cfg.switch_out, din); vec(f"sw.{i}.b", f"switch.{i}.bias", cfg.switch_out)
         din = cfg.switch_out
     tab("dec.emb", "dec.embed_tokens", V, H)
+    if cfg.dec_arch == 1:       # OPT / Galactica: nothing folded (LayerNorm has a mean), biases kept as fp32 vectors
+        tab("dec.pos", "dec.embed_positions", cfg.dec_max_pos + 2, H)
+        for l in range(cfg.dec_layers):
+            s, d = f"dec.layers.{l}.", f"dec.{l}."
+            vec(d + "ln1.w", s + "ln1.weight", H); vec(d + "ln1.b", s + "ln1.bias", H)
+            out.append(_cat(d + "wqkv", True, H, [(s + "q.weight", cfg.dec_q_dim), (s + "k.weight", cfg.dec_kv_dim),
+                                                 (s + "v.weight", cfg.dec_kv_dim)], True))
+            out.append(_cat(d + "bqkv", False, 1, [(s + "q.bias", cfg.dec_q_dim), (s + "k.bias", cfg.dec_kv_dim),
+                                                  (s + "v.bias", cfg.dec_kv_dim)]))
+            mat(d + "wo", s + "o.weight", H, cfg.dec_q_dim); vec(d + "bo", s + "o.bias", H)
+            vec(d + "ln2.w", s + "ln2.weight", H); vec(d + "ln2.b", s + "ln2.bias", H)
+            mat(d + "w1", s + "fc1.weight", F, H); vec(d + "b1", s + "fc1.bias", F)
+            mat(d + "w2", s + "fc2.weight", H, F); vec(d + "b2", s + "fc2.bias", H)
+        vec("dec.lnf.w", "dec.norm.weight", H); vec("dec.lnf.b", "dec.norm.bias", H)
+        mat("dec.lm_head", "dec.lm_head.weight", V, H)
+        return out
     for l in range(cfg.dec_layers):
         s, d = f"dec.layers.{l}.", f"dec.{l}."
         out.append(_cat(d + "wqkv", True, H, [(s + "q.weight", cfg.dec_q_dim), (s + "k.weight", cfg.dec_kv_dim),
                                              (s + "v.weight", cfg.dec_kv_dim)], True, s + "input_norm.weight"))
+        if cfg.dec_qkv_bias:    # Qwen2: the bias is added after the (folded-norm) projection, so it is not folded
+            out.append(_cat(d + "bqkv", False, 1, [(s + "q.bias", cfg.dec_q_dim), (s + "k.bias", cfg.dec_kv_dim),
+                                                  (s + "v.bias", cfg.dec_kv_dim)]))
         mat(d + "wo", s + "o.weight", H, cfg.dec_q_dim)
         out.append(Fused(d + "wgu", True, (2 * F, H), (Part(s + "gate.weight", F, H, 16, 32, 0),
                                                        Part(s + "up.weight", F, H, 16, 32, 16)),

@@ -19,7 +19,8 @@ every one of them.
 from .esm2 import esm2_batch_tokens, esm2_hidden, esm2_pool, esm2_encode  # noqa: F401
 from .projector import protein_projector, switch_projector  # noqa: F401
 from .splice import tokenizer_seq_token, left_pad_sequence, splice_and_pad  # noqa: F401
-from .llama import llama_forward, greedy_decode, KVCache  # noqa: F401
+from .llama import llama_forward, greedy_decode, decoder_forward_fn, KVCache  # noqa: F401
+from .opt import opt_forward  # noqa: F401
 from .lora import lora_merge  # noqa: F401
 from .pipeline import OraclePipeline  # noqa: F401
 from .sampling import sampling_distribution  # noqa: F401

@@ -63,9 +63,10 @@ def llama_forward(embeds: torch.Tensor, mask: torch.Tensor, W: Dict[str, torch.T
     for l in range(cfg.dec_layers):
         p = f"dec.layers.{l}."
         h = _rms(x, W[p + "input_norm.weight"], cfg.dec_rms_eps)
-        q = F.linear(R(h), W[p + "q.weight"]).view(B, Tq, nh, hd).transpose(1, 2)
-        k = F.linear(R(h), W[p + "k.weight"]).view(B, Tq, nkv, hd).transpose(1, 2)
-        v = F.linear(R(h), W[p + "v.weight"]).view(B, Tq, nkv, hd).transpose(1, 2)
+        # q/k/v biases: Qwen2 (transformers/models/qwen2/modeling_qwen2.py, `bias=True` on q_proj/k_proj/v_proj only)
+        q = F.linear(R(h), W[p + "q.weight"], W.get(p + "q.bias")).view(B, Tq, nh, hd).transpose(1, 2)
+        k = F.linear(R(h), W[p + "k.weight"], W.get(p + "k.bias")).view(B, Tq, nkv, hd).transpose(1, 2)
+        v = F.linear(R(h), W[p + "v.weight"], W.get(p + "v.bias")).view(B, Tq, nkv, hd).transpose(1, 2)
         q, k = _rope(q, pos, cfg.dec_rope_theta), _rope(k, pos, cfg.dec_rope_theta)
         k, v = R(k), R(v)                                       # the KV cache holds the model dtype
         if cache is not None and cache.k:
@@ -90,6 +91,14 @@ def llama_forward(embeds: torch.Tensor, mask: torch.Tensor, W: Dict[str, torch.T
     return F.linear(R(x), W["dec.lm_head.weight"]), new
 
 
+def decoder_forward_fn(cfg):
+    """The decoder family of the config (model/builder.py:60-92): Llama / Qwen2 here, OPT / Galactica in opt.py."""
+    if getattr(cfg, "dec_arch", 0) == 1:
+        from .opt import opt_forward
+        return opt_forward
+    return llama_forward
+
+
 def greedy_decode(embeds: torch.Tensor, mask: torch.Tensor, W, cfg, max_new_tokens: int,
                   eos_ids: Sequence[int] = (), pad_id: int = 0, R: Callable = Ident,
                   forced: Optional[torch.Tensor] = None
@@ -105,7 +114,8 @@ def greedy_decode(embeds: torch.Tensor, mask: torch.Tensor, W, cfg, max_new_toke
     emb_table = W["dec.embed_tokens"]
     eos = torch.tensor(list(eos_ids), dtype=torch.long)
     unfinished = torch.ones(B, dtype=torch.long)
-    logits, cache = llama_forward(embeds, mask, W, cfg, None, R)
+    forward = decoder_forward_fn(cfg)
+    logits, cache = forward(embeds, mask, W, cfg, None, R)
     out, margins, all_logits = [], [], []
     for step in range(max_new_tokens):
         top2 = logits.topk(2, dim=-1).values
@@ -121,5 +131,5 @@ def greedy_decode(embeds: torch.Tensor, mask: torch.Tensor, W, cfg, max_new_toke
         if unfinished.max() == 0 or step + 1 == max_new_tokens:
             break
         mask = torch.cat([mask, torch.ones(B, 1, dtype=torch.bool)], dim=1)
-        logits, cache = llama_forward(emb_table[nxt][:, None, :], mask, W, cfg, cache, R)
+        logits, cache = forward(emb_table[nxt][:, None, :], mask, W, cfg, cache, R)
     return torch.stack(out, 1), torch.stack(margins, 1), torch.stack(all_logits, 0)

@@ -57,7 +57,7 @@ def micro(dev):
 # ------------------------------------------------------------------------------------------------
 def test_native_library_is_loaded():
     from opus_pllm_amd import _cabi
-    assert _cabi.lib().opus_abi_version() == 1
+    assert _cabi.lib().opus_abi_version() == _cabi.ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "libopus_pllm.so" in maps
 
@@ -501,3 +501,31 @@ def test_midsize_path_vs_oracle(dev):
     for s in range(3):
         lg = model.decode_logits(ref_ids[:, s]).cpu()
         assert rel_l2(lg, ref_logits[s + 1]) < 2 * REL_L2, s
+
+
+# ------------------------------------------------------------------------------------------------ N4: decoder families
+@pytest.mark.parametrize("tag,preset", [("generate_micro_opt", "micro_opt"), ("generate_micro_qwen", "micro_qwen")])
+@pytest.mark.parametrize("on_gpu_fill", [False, True])
+def test_decoder_family_golden(dev, gold, tag, preset, on_gpu_fill):
+    """OPT / Galactica (learned positions, LayerNorm, biases, fc1-GELU-fc2) and Qwen2 (q/k/v biases) decoders against
+    the transformers goldens: prefill + 4 teacher-forced step logits, greedy ids, hipGraph replay; weights both from
+    the canonical host tensors and from the on-device synthetic fill."""
+    cfg = opa.PRESETS[preset]()
+    model, W = make_model(cfg, dev, synthetic_on_gpu=on_gpu_fill)
+    base, g = gold("generate_micro"), gold(tag)
+    emb = torch.from_numpy(base["embeds"]).half()
+    mask = torch.from_numpy(base["mask_out"]).bool()
+    ref = torch.from_numpy(g["step_logits"])
+    free = torch.from_numpy(g["free_ids"])
+    lg = model.prefill_logits(emb, mask).cpu()
+    assert rel_l2(lg, ref[:, 0]) < REL_L2
+    for s in range(4):
+        lg = model.decode_logits(free[:, s]).cpu()
+        assert rel_l2(lg, ref[:, s + 1]) < REL_L2, s
+        assert torch.equal(lg.argmax(-1), ref[:, s + 1].argmax(-1))
+    import oracle
+    _, margins, _ = oracle.greedy_decode(emb.float(), mask, W, cfg, free.shape[1], (), 2)
+    out = model._greedy(emb.to(dev), mask.to(dev), free.shape[1], [], 2)
+    # bit-exact ids up to each row's first low-margin step (these fixtures do contain near-ties)
+    assert _check_ids(out, free, margins) >= 0.7
+    assert torch.equal(model._greedy(emb.to(dev), mask.to(dev), free.shape[1], [], 2), out)     # graph replay

@@ -107,8 +107,13 @@ def test_missing_artefacts_fail_without_network(tmp_path, monkeypatch):
     monkeypatch.setenv("OPUS_ESM2_CKPT", str(tmp_path / "nope.pt"))
     with pytest.raises(FileNotFoundError):
         builder._esm2_ckpt_path()
+    with pytest.raises(NotImplementedError):                # a family the reference does not dispatch either (builder.py:96)
+        builder.load_pretrained_model("/models/mistral-7b", None, "mistral", device="cuda:0")
+    with pytest.raises(NotImplementedError):                # post-LayerNorm / ReLU / projected-embedding OPT variants
+        builder.config_from_hf(dict(model_type="opt", hidden_size=1024, num_attention_heads=16, do_layer_norm_before=False))
     with pytest.raises(NotImplementedError):
-        builder.load_pretrained_model("/models/opt-350m", None, "opt", device="cuda:0")
+        builder.config_from_hf(dict(model_type="opt", hidden_size=2048, num_attention_heads=32, activation_function="relu",
+                                    ffn_dim=8192, num_hidden_layers=2, vocab_size=100))
 
 
 @pytest.mark.gpu
@@ -223,3 +228,50 @@ def test_two_stage_pipeline_matches_one_stage(tmp_path):
     b = model.generate(ids, [seqs[i] for i in rows], attention_mask=mask, pad_token_id=tok.eos_token_id, max_new_tokens=8,
                        seq_embedding=emb)
     assert torch.equal(a, b)
+
+
+def test_opt_and_qwen_state_dict_mappings_roundtrip():
+    """canonical_from_hf_opt / canonical_from_hf_llama (Qwen2 biases) invert the naming of the transformers state dicts;
+    absent OPT biases / LayerNorm parameters become zeros / ones, an absent lm_head is the tied embedding."""
+    cfg = opa.micro_opt()
+    canon = {k: torch.from_numpy(v) for k, v in synth.canonical_weights(cfg, 0).items()}
+    sd = {"model.decoder.embed_tokens.weight": canon["dec.embed_tokens"], "model.decoder.embed_positions.weight": canon["dec.embed_positions"],
+          "model.decoder.final_layer_norm.weight": canon["dec.norm.weight"], "model.decoder.final_layer_norm.bias": canon["dec.norm.bias"],
+          "lm_head.weight": canon["dec.lm_head.weight"]}
+    names = (("ln1", "self_attn_layer_norm"), ("q", "self_attn.q_proj"), ("k", "self_attn.k_proj"), ("v", "self_attn.v_proj"),
+             ("o", "self_attn.out_proj"), ("ln2", "final_layer_norm"), ("fc1", "fc1"), ("fc2", "fc2"))
+    for l in range(cfg.dec_layers):
+        for a, b in names:
+            for p in ("weight", "bias"):
+                sd[f"model.decoder.layers.{l}.{b}.{p}"] = canon[f"dec.layers.{l}.{a}.{p}"]
+    got = builder.canonical_from_hf_opt(sd, cfg)
+    dec = {k: v for k, v in canon.items() if k.startswith("dec.")}
+    assert set(got) == set(dec) and all(torch.equal(got[k], dec[k]) for k in dec)
+    bare = {k.replace("model.decoder.", "decoder."): v for k, v in sd.items() if not k.endswith(".bias") and "layer_norm" not in k
+            and k != "lm_head.weight"}
+    g2 = builder.canonical_from_hf_opt(bare, cfg)
+    assert torch.equal(g2["dec.lm_head.weight"], canon["dec.embed_tokens"])
+    assert float(g2["dec.layers.0.q.bias"].abs().max()) == 0.0 and float(g2["dec.layers.1.ln2.weight"].min()) == 1.0
+    hf = dict(model_type="opt", hidden_size=64, num_attention_heads=4, ffn_dim=128, num_hidden_layers=2, vocab_size=96,
+              activation_function="gelu", do_layer_norm_before=True, word_embed_proj_dim=64, max_position_embeddings=96)
+    c2 = builder.config_from_hf(hf, max_prompt=48, max_new_tokens=16)
+    assert (c2.dec_arch, c2.dec_kv_heads, c2.dec_head_dim, c2.dec_ffn, c2.dec_max_pos) == (1, 4, 16, 128, 96)
+    q = opa.micro_qwen()
+    cq = {k: torch.from_numpy(v) for k, v in synth.canonical_weights(q, 0).items()}
+    sdq = {"model.embed_tokens.weight": cq["dec.embed_tokens"], "model.norm.weight": cq["dec.norm.weight"],
+           "lm_head.weight": cq["dec.lm_head.weight"]}
+    for l in range(q.dec_layers):
+        s, d = f"dec.layers.{l}.", f"model.layers.{l}."
+        sdq[d + "input_layernorm.weight"] = cq[s + "input_norm.weight"]
+        sdq[d + "post_attention_layernorm.weight"] = cq[s + "post_norm.weight"]
+        for a in ("q", "k", "v", "o"):
+            sdq[d + f"self_attn.{a}_proj.weight"] = cq[s + a + ".weight"]
+        for a in ("q", "k", "v"):
+            sdq[d + f"self_attn.{a}_proj.bias"] = cq[s + a + ".bias"]
+        for a in ("gate", "up", "down"):
+            sdq[d + f"mlp.{a}_proj.weight"] = cq[s + a + ".weight"]
+    gq = builder.canonical_from_hf_llama(sdq, q)
+    decq = {k: v for k, v in cq.items() if k.startswith("dec.")}
+    assert set(gq) == set(decq) and all(torch.equal(gq[k], decq[k]) for k in decq)
+    assert builder.config_from_hf(dict(model_type="qwen2", hidden_size=64, num_attention_heads=4, num_key_value_heads=2,
+                                       intermediate_size=128, num_hidden_layers=2, vocab_size=96, rope_theta=1e6)).dec_qkv_bias == 1

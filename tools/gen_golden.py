@@ -337,6 +337,70 @@ def gold_c1(cfg, w):
 
 
 
+def gold_decoder_family(tag, cfg, w):
+    """Row N4: decoder families other than Llama.  The reference's wrappers (opus_opt.py, opus_qwen.py) only route
+    `inputs_embeds` into the stock transformers model, so the golden is the LOCAL transformers OPTForCausalLM /
+    Qwen2ForCausalLM run on the spliced embeddings of generate_micro (same prompt rows, same protein features):
+    prefill + 4 teacher-forced step logits in one forward, and the greedy ids of generate(inputs_embeds=...)."""
+    from transformers import OPTConfig, OPTForCausalLM, Qwen2Config, Qwen2ForCausalLM
+    g = np.load(os.path.join(GOLD, "generate_micro.npz"))
+    emb = torch.from_numpy(g["embeds"]).float()
+    amask = torch.from_numpy(g["mask_out"]).long()
+    if cfg.dec_arch == 1:
+        hc = OPTConfig(vocab_size=cfg.dec_vocab, hidden_size=cfg.dec_dim, ffn_dim=cfg.dec_ffn, num_hidden_layers=cfg.dec_layers,
+                       num_attention_heads=cfg.dec_heads, max_position_embeddings=cfg.dec_max_pos,
+                       word_embed_proj_dim=cfg.dec_dim, do_layer_norm_before=True, activation_function="gelu",
+                       enable_bias=True, layer_norm_elementwise_affine=True, dropout=0.0, tie_word_embeddings=False,
+                       pad_token_id=None, bos_token_id=1, eos_token_id=None)
+        hc._attn_implementation = "eager"
+        model = OPTForCausalLM(hc).eval()
+        sd = {"model.decoder.embed_tokens.weight": tw(w, "dec.embed_tokens"),
+              "model.decoder.embed_positions.weight": tw(w, "dec.embed_positions"),
+              "model.decoder.final_layer_norm.weight": tw(w, "dec.norm.weight"),
+              "model.decoder.final_layer_norm.bias": tw(w, "dec.norm.bias"), "lm_head.weight": tw(w, "dec.lm_head.weight")}
+        for l in range(cfg.dec_layers):
+            s_, d = f"dec.layers.{l}.", f"model.decoder.layers.{l}."
+            for a, b in (("ln1", "self_attn_layer_norm"), ("q", "self_attn.q_proj"), ("k", "self_attn.k_proj"),
+                         ("v", "self_attn.v_proj"), ("o", "self_attn.out_proj"), ("ln2", "final_layer_norm"),
+                         ("fc1", "fc1"), ("fc2", "fc2")):
+                for p in ("weight", "bias"):
+                    sd[d + b + "." + p] = tw(w, s_ + a + "." + p)
+    else:
+        hc = Qwen2Config(vocab_size=cfg.dec_vocab, hidden_size=cfg.dec_dim, intermediate_size=cfg.dec_ffn,
+                         num_hidden_layers=cfg.dec_layers, num_attention_heads=cfg.dec_heads,
+                         num_key_value_heads=cfg.dec_kv_heads, rms_norm_eps=cfg.dec_rms_eps, rope_theta=cfg.dec_rope_theta,
+                         max_position_embeddings=2048, tie_word_embeddings=False, use_sliding_window=False,
+                         pad_token_id=None, bos_token_id=1, eos_token_id=None)
+        hc._attn_implementation = "eager"
+        model = Qwen2ForCausalLM(hc).eval()
+        sd = {"model.embed_tokens.weight": tw(w, "dec.embed_tokens"), "model.norm.weight": tw(w, "dec.norm.weight"),
+              "lm_head.weight": tw(w, "dec.lm_head.weight")}
+        for l in range(cfg.dec_layers):
+            s_, d = f"dec.layers.{l}.", f"model.layers.{l}."
+            sd[d + "input_layernorm.weight"] = tw(w, s_ + "input_norm.weight")
+            sd[d + "post_attention_layernorm.weight"] = tw(w, s_ + "post_norm.weight")
+            for a in ("q", "k", "v"):
+                sd[d + f"self_attn.{a}_proj.weight"] = tw(w, s_ + a + ".weight")
+                sd[d + f"self_attn.{a}_proj.bias"] = tw(w, s_ + a + ".bias")
+            sd[d + "self_attn.o_proj.weight"] = tw(w, s_ + "o.weight")
+            for a in ("gate", "up", "down"):
+                sd[d + f"mlp.{a}_proj.weight"] = tw(w, s_ + a + ".weight")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing if "inv_freq" not in k] and not unexpected, (missing, unexpected)
+    assert model.lm_head.weight.data_ptr() != model.get_input_embeddings().weight.data_ptr()
+    N = 12
+    with torch.no_grad():
+        free = model.generate(inputs_embeds=emb, attention_mask=amask, do_sample=False, max_new_tokens=N, use_cache=True,
+                              pad_token_id=2, eos_token_id=None)
+        assert free.shape == (emb.shape[0], N), free.shape
+        full = torch.cat([emb, model.get_input_embeddings()(free[:, :4])], dim=1)
+        fmask = torch.cat([amask, torch.ones(emb.shape[0], 4, dtype=amask.dtype)], dim=1)
+        kw = {} if cfg.dec_arch == 1 else dict(position_ids=(fmask.cumsum(-1) - 1).clamp(min=0))
+        logits = model(inputs_embeds=full, attention_mask=fmask, **kw).logits
+    T = emb.shape[1]
+    save(tag, free_ids=free.numpy(), step_logits=logits[:, T - 1:T + 4].numpy())
+
+
 def gold_conversation():
     """Prompt renderings of the reference's conversation module (row N2): every separator style it renders, the
     presets, and the ChatML fallback template through a transformers tokenizer's apply_chat_template."""
@@ -388,6 +452,8 @@ def main():
     print("projector"); gold_projector(cfg, w, model)
     print("splice"); gold_splice(cfg, w, model)
     print("llama + generate (micro)"); gold_llama_and_generate(cfg, w, model, hf)
+    for tag, fam in (("generate_micro_opt", opa.micro_opt()), ("generate_micro_qwen", opa.micro_qwen())):
+        print(tag); gold_decoder_family(tag, fam, synth.canonical_weights(fam, seed=0))
     print("C1 chain")
     c1 = opa.c1_tiny()
     gold_c1(c1, synth.canonical_weights(c1, seed=0))
