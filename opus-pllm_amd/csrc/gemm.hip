@@ -825,26 +825,35 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8 *>(base + boff + j * 1024);
     };
-    auto mfmas = [&](const h8 (&af)[TM], const h8 (&bf)[TN]) {
-        __builtin_amdgcn_s_setprio(1);
+    auto mfmas = [&](const h8 (&af)[TM], const h8 (&bf)[TN], int i0, int i1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
+            if (i >= i0 && i < i1) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
-        __builtin_amdgcn_s_setprio(0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
+            }
     };
     const int last = KS - 1;
     auto issued_upto = [&](int x) { return x < last ? x : last; };
+    // The fragment reads of stage ks+1 are placed AFTER the first row of MFMAs of stage ks: the compiler's waitcnt pass
+    // cannot see through the hand-placed counters and puts a full LDS wait in front of the first MFMA that follows a
+    // ds_read; there it only covers the (long finished) reads of the previous iteration, and the twelve new reads run
+    // under the remaining 28 MFMAs instead of in front of all 32.
     auto step = [&](int ks, const h8 (&ca)[TM], const h8 (&cb)[TN], h8 (&na)[TM], h8 (&nb)[TN]) {
         if (ks + 1 < KS) {
             wait_glds(issued_upto(ks + NS - 1) - (ks + 1));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // WAR: this wave's reads of slot ks are done
             __builtin_amdgcn_s_barrier();
             if (ks + NS < KS) stage_load(ks + NS);
-            read_frags(ks + 1, na, nb);
         }
-        mfmas(ca, cb);
+        __builtin_amdgcn_s_setprio(1);
+        mfmas(ca, cb, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < KS) read_frags(ks + 1, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(ca, cb, 1, TM);
+        __builtin_amdgcn_s_setprio(0);
     };
     h8 a0[TM], b0[TN], a1[TM], b1[TN];
 #pragma unroll
@@ -951,7 +960,7 @@ template <int MT, int EPI>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MP = 16 * MT;
-    constexpr int SC = 8;                                            // 64-k chunks per stage
+    constexpr int SC = MT <= 4 ? 8 : 4;                              // 64-k chunks per stage (2 stages <= 128 KB of LDS)
     constexpr int CIMG = MP * 128;                                   // bytes of one chunk image [MP][64] fp16
     constexpr int STAGE = SC * CIMG;
     constexpr int NPIECE = SC * MP / 8;                              // 1-KB DMA pieces per stage (8 rows x 128 B)
@@ -1096,7 +1105,7 @@ static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
         while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
         if (ks < 1) ks = 1;
     }
-    const int lds = 2 * 8 * 16 * MT * 128;
+    const int lds = 2 * (MT <= 4 ? 8 : 4) * 16 * MT * 128;
     static bool attr = false;
     if (!attr) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_kernel<MT, EPI>),
@@ -1266,6 +1275,14 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
             case EPI_NONE: return launch_mid_e<EPI_NONE, false>(p, s);
             case EPI_GELU: return launch_mid_e<EPI_GELU, false>(p, s);
             case EPI_SILU_GU16: return launch_mid_e<EPI_SILU_GU16, false>(p, s);
+        }
+    } else if (!p.Af && p.M <= 96 && p.N >= 16384 && !mid_v1) {
+        // 65..96 rows and a wide output (gate/up of the B = 1 prefill): still a weight stream; six row tiles per wave
+        // keep it one pass over the weights (47 vs 62 us for the split-K tile kernel; narrow outputs measured slower)
+        switch (p.epi) {
+            case EPI_NONE: return launch_wide<6, EPI_NONE>(p, s);
+            case EPI_GELU: return launch_wide<6, EPI_GELU>(p, s);
+            case EPI_SILU_GU16: return launch_wide<6, EPI_SILU_GU16>(p, s);
         }
     } else {
         switch (p.epi) {
