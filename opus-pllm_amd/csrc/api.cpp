@@ -769,7 +769,7 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
         sp.cs = c->cs_dec; sp.kstart = c->d_kstart; sp.step = c->d_step; sp.T0 = T;
         sp.kc = c->kc; sp.vc = c->vc; sp.cache_sl = c->cache_sl; sp.cache_sb = c->cache_sb; sp.cache_sh = c->cache_sh;
         sp.ctx_cap = ctx_cap; sp.bar = c->d_bar;
-        sp.seg_max = sp.xs_bytes = sp.red_floats = sp.flags = 0;
+        sp.seg_max = sp.xs_bytes = sp.red_floats = 0;
         sp.trace = nullptr; sp.trace_block = 0;
         static const char *trace_env = getenv("OPUS_STACK_TRACE");     // tuning aid: workgroup id to trace
         if (trace_env) {

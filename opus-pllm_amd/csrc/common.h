@@ -126,7 +126,7 @@ struct StackParams {
     int ctx_cap;
     unsigned *bar;              // [0] arrivals, [1] finished workgroups, [2] timeout flag, [1024 + 1024 k] go words
                                 //   (all zero between launches)
-    int seg_max, xs_bytes, red_floats, flags;   // filled by the launcher
+    int seg_max, xs_bytes, red_floats;   // filled by the launcher
     unsigned long long *trace;  // tuning aid: timeline of workgroup trace_block in layer 1 (or nullptr)
     int trace_block;
 };

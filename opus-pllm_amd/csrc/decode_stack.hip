@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(StackParams p) {
         }
     };
     auto wait = [&]() __attribute__((always_inline)) {
-        if (tid == 0 && !dead && !(p.flags & 2)) {
+        if (tid == 0 && !dead) {
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
                 __builtin_amdgcn_s_sleep(8);
@@ -568,7 +568,6 @@ static hipError_t launch_hd(StackParams p, hipStream_t s, hipEvent_t ev0, hipEve
     seg = std::max(seg, segs(p.H >> 4, 1, p.F >> 6));
     seg = std::max(seg, segs((p.V + 15) >> 4, 1, p.H >> 6));
     p.seg_max = seg;
-    p.flags = getenv("OPUS_STACK_FLAGS") ? atoi(getenv("OPUS_STACK_FLAGS")) : 0;   // timing experiments only
     const int DV = HD / 8, PARTS = NT / DV;
     const size_t attn_bytes = ((size_t)3 * HD + p.ctx_cap + (size_t)PARTS * HD) * sizeof(float);
     size_t xs_bytes = std::max((size_t)p.B * Kmax * sizeof(half_t), attn_bytes);
