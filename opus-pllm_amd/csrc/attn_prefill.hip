@@ -72,25 +72,68 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     half_t *myP = sP + wave * 16 * (KB + VPAD);
     const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
 
+    // K/V tiles are double-buffered through registers: the global loads of tile t+1 are issued right after tile t has
+    // been copied into LDS, so their latency runs under the MFMA / softmax work of tile t.
+    constexpr int KL = KB * CH / 256;            // 16-B pieces of K per thread and tile
+    constexpr int VN = KB * (HD / 8);            // 16-B pieces of V per tile (128 for head_dim 16: half the threads idle)
+    constexpr int VL = VN >= 256 ? VN / 256 : 1;
+    static_assert(KL >= 1, "tile too small for 256 threads");
+    h8 kreg[KL], vreg[VL];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < KL; ++u) {
+            const int i = tid + 256 * u, r = i / CH, c = i % CH;
+            int kr = kt + r;
+            kr = kr < p.T ? kr : p.T - 1;
+            kreg[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (c * 8 < HD) kreg[u] = *reinterpret_cast<const h8 *>(Kb + (int64_t)kr * p.k_st + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < VL; ++u) {
+            const int i = tid + 256 * u, r = i / (HD / 8), c = i % (HD / 8);
+            int kr = kt + r;
+            kr = kr < p.T ? kr : p.T - 1;
+            vreg[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (i < VN) vreg[u] = *reinterpret_cast<const h8 *>(Vb + (int64_t)kr * p.v_st + c * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < KL; ++u) {
+            const int i = tid + 256 * u, r = i / CH, c = i % CH;
+            *reinterpret_cast<h8 *>(sK + r * HDP + kswz<HDP>(r, c) * 8) = kreg[u];
+        }
+        // V^T: lanes (r, c) and (r^1, c) sit HD/8 lanes apart; they swap halves of their 8 dims so that each writes
+        // four {key r&~1, key r|1} pairs as 32-bit words instead of eight 16-bit ones
+#pragma unroll
+        for (int u = 0; u < VL; ++u) {
+            const int i = tid + 256 * u, r = i / (HD / 8), c = i % (HD / 8);
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const u4v mine = __builtin_bit_cast(u4v, vreg[u]);
+            const bool odd = r & 1;
+            // send the half the partner writes, keep the half this lane writes (even rows: dims 0..3, odd rows: 4..7)
+            const unsigned s0 = odd ? mine[0] : mine[2], s1 = odd ? mine[1] : mine[3];
+            const unsigned k0 = odd ? mine[2] : mine[0], k1 = odd ? mine[3] : mine[1];
+            const unsigned o0 = __shfl_xor(s0, HD / 8, 64), o1 = __shfl_xor(s1, HD / 8, 64);
+            // k0/k1: this lane's key, two dims per word; o0/o1: the partner key, same dims
+            const unsigned lo0 = odd ? o0 : k0, hi0 = odd ? k0 : o0;     // even key in the low half of each output word
+            const unsigned lo1 = odd ? o1 : k1, hi1 = odd ? k1 : o1;
+            const int d0 = c * 8 + (odd ? 4 : 0), re = r & ~1;
+            unsigned *dst = reinterpret_cast<unsigned *>(sVt);
+            constexpr int RW = (KB + VPAD) / 2;                           // words per V^T row
+            if (i >= VN) continue;
+            dst[(d0 + 0) * RW + (re >> 1)] = (lo0 & 0xffffu) | (hi0 << 16);
+            dst[(d0 + 1) * RW + (re >> 1)] = (lo0 >> 16) | (hi0 & 0xffff0000u);
+            dst[(d0 + 2) * RW + (re >> 1)] = (lo1 & 0xffffu) | (hi1 << 16);
+            dst[(d0 + 3) * RW + (re >> 1)] = (lo1 >> 16) | (hi1 & 0xffff0000u);
+        }
+    };
+
+    if (k_lo < k_hi) load_tile(k_lo);
     for (int kt = k_lo; kt < k_hi; kt += KB) {
         __syncthreads();   // previous tile fully consumed
-        // ---- stage K (row-major, swizzled) and V (transposed) ----
-        for (int i = tid; i < KB * CH; i += 256) {
-            const int r = i / CH, c = i % CH;
-            int kr = kt + r;
-            kr = kr < p.T ? kr : p.T - 1;
-            h8 v = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (c * 8 < HD) v = *reinterpret_cast<const h8 *>(Kb + (int64_t)kr * p.k_st + c * 8);
-            *reinterpret_cast<h8 *>(sK + r * HDP + kswz<HDP>(r, c) * 8) = v;
-        }
-        for (int i = tid; i < KB * (HD / 8); i += 256) {
-            const int r = i / (HD / 8), c = i % (HD / 8);
-            int kr = kt + r;
-            kr = kr < p.T ? kr : p.T - 1;
-            const h8 v = *reinterpret_cast<const h8 *>(Vb + (int64_t)kr * p.v_st + c * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sVt[(c * 8 + j) * (KB + VPAD) + r] = v[j];
-        }
+        store_tile();
+        if (kt + KB < k_hi) load_tile(kt + KB);
         __syncthreads();
 
         // ---- S = Q K^T : 4 column tiles of 16 keys ----
@@ -106,6 +149,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
             }
         }
         // ---- mask + online softmax (row = 4g + r, key = kt + 16n + li) ----
+        // interior: every key of the tile is visible to every query row of this workgroup (block-uniform)
+        const bool interior = kt >= kstart && kt + KB <= kend && (!CAUSAL || kt + KB - 1 <= q0);
         float alpha[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -113,10 +158,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
             float mx = -INFINITY;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int kj = kt + 16 * n + li;
-                bool vis = kj >= kstart && kj < kend;
-                if (CAUSAL) vis = vis && kj <= qi;
-                const float v = vis ? s[n][r] * sc : -INFINITY;
+                float v = s[n][r] * sc;
+                if (!interior) {                                     // tiles that touch a padding / causal boundary
+                    const int kj = kt + 16 * n + li;
+                    bool vis = kj >= kstart && kj < kend;
+                    if (CAUSAL) vis = vis && kj <= qi;
+                    v = vis ? v : -INFINITY;
+                }
                 s[n][r] = v;
                 mx = fmaxf(mx, v);
             }
