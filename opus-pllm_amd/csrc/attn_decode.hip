@@ -146,23 +146,51 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
     }
     __syncthreads();
 
-    // ---- softmax per head (fp32) ----
-    float linv[GP];
+    // ---- softmax per head (fp32); the GP heads share each block-wide reduction (2 barriers instead of 2 GP) ----
+    float linv[GP], mx[GP], sum[GP];
+    __shared__ float redv[4][GP];
+    auto reduce_all = [&](float (&v)[GP], bool is_max) {
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float t = __shfl_xor(v[gi], o, 64);
+                v[gi] = is_max ? fmaxf(v[gi], t) : v[gi] + t;
+            }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int gi = 0; gi < GP; ++gi) redv[tid >> 6][gi] = v[gi];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi) {
+            float r = redv[0][gi];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, redv[w][gi]) : r + redv[w][gi];
+            v[gi] = r;
+        }
+    };
 #pragma unroll
     for (int gi = 0; gi < GP; ++gi) {
-        float mx = -INFINITY;
-        for (int j = tid; j < nkeys; j += 256) mx = fmaxf(mx, sc[gi * ctx_cap + j]);
-        mx = block_reduce(mx, true, scratch);
-        float sum = 0.f;
+        mx[gi] = -INFINITY;
+        for (int j = tid; j < nkeys; j += 256) mx[gi] = fmaxf(mx[gi], sc[gi * ctx_cap + j]);
+    }
+    reduce_all(mx, true);
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi) {
+        sum[gi] = 0.f;
         for (int j = tid; j < nkeys; j += 256) {
-            const float e = __expf(sc[gi * ctx_cap + j] - mx);
+            const float e = __expf(sc[gi * ctx_cap + j] - mx[gi]);
             // P is rounded to fp16 before the PV product, as the prefill kernel and HF (softmax .to(q.dtype))
             sc[gi * ctx_cap + j] = (float)(half_t)e;
-            sum += e;
+            sum[gi] += e;
         }
-        sum = block_reduce(sum, false, scratch);
-        linv[gi] = 1.0f / sum;
     }
+    reduce_all(sum, false);
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi) linv[gi] = 1.0f / sum[gi];
     __syncthreads();
 
     // ---- O = P V : thread = (8-wide column slice, key partition) ----
