@@ -1203,8 +1203,13 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
         attr_set = true;
     }
     static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr;   // A/B aid
-    if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192)   // enough 256 x 256 tiles to fill the chip
+    if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) {   // enough 256 x 256 tiles to fill the chip
+        // short reductions with a heavy epilogue (fp32 residual read-modify-write, GELU): 128 x 128 tiles, two workgroups
+        // per CU, so one workgroup's epilogue runs under the other's MFMAs (+8..20 % on the ESM wo / fc1 and decoder wo
+        // shapes; long-K and plain-store shapes measured faster on the 256 x 256 tile)
+        if ((p.residual || EPI == EPI_GELU) && p.K <= 4096) return launch_ring<4, 2, 4, EPI>(p, s, false);
         return launch_ring<8, 4, 4, EPI>(p, s, false);
+    }
     // Too few output tiles to fill 256 CUs (B = 1 prefill, single-protein encoder): split K so that
     // ~256-320 workgroups stream the weights, at least 4 k-tiles each, slabs within the workspace.
     const int ntile = tm * tn, KT = p.K / TBK;
