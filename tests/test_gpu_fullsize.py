@@ -118,3 +118,40 @@ def test_capacity_errors(big):
         model.generate(ids, seqs, max_new_tokens=64)                        # > max_new_tokens
     with pytest.raises(OpusError):
         model.generate(torch.cat([ids, ids], dim=1), seqs * 2, max_new_tokens=4)   # 2 x 96 positions > max_prompt
+
+
+@pytest.mark.parametrize("preset", ["galactica_1_3b", "qwen2_7b"])
+def test_other_decoder_families_at_full_size(preset):
+    """Row N4 at the released shapes (OPT-architecture Galactica-1.3B; Qwen2.5-7B with q/k/v biases): KV-cache
+    consistency (decode step == prefill of the longer prompt), determinism under graph replay, left-pad invariance."""
+    from opus_pllm_amd.model import OpusLlamaForCausalLM
+    from opus_pllm_amd.weights import DeviceWeights
+    dev = torch.device("cuda:0")
+    cfg = opa.PRESETS[preset](max_batch=2, max_enc_tokens=258, max_prompt=104, max_new_tokens=8)
+    model = OpusLlamaForCausalLM(cfg, DeviceWeights.synthetic(cfg, 0, dev), dev)
+    try:
+        seqs = [synth.synth_protein(200 + 37 * i, i) for i in range(2)]
+        ids = torch.tensor([synth.synth_prompt_ids(cfg.dec_vocab, i, n_text=89) for i in range(2)])
+        prot = model.switch_projector_embedding(model.encode_projector_embedding(model.encode_seq2embedding(seqs)))
+        emb, mask, _ = model._splice(ids, None, prot, True)
+        lg0 = model.prefill_logits(emb, mask)
+        tok = lg0.argmax(-1)
+        lg1 = model.decode_logits(tok)
+        emb2 = torch.cat([emb, model.get_model().embed_tokens(tok)[:, None, :]], dim=1)
+        mask2 = torch.cat([mask, torch.ones_like(mask[:, :1])], dim=1)
+        ref = model.prefill_logits(emb2, mask2)
+        rel = (lg1 - ref).norm() / ref.norm()
+        assert float(rel) < 5e-3, float(rel)
+        assert torch.equal(lg1.argmax(-1), ref.argmax(-1))
+        a = model.generate(ids, seqs, max_new_tokens=8, pad_token_id=0)
+        b = model.generate(ids, seqs, max_new_tokens=8, pad_token_id=0)
+        assert a.shape == (2, 8) and torch.equal(a, b)
+        # row 1 alone, left-padded by 5 positions: same first tokens as in the batch
+        pad_ids = torch.cat([torch.zeros(1, 5, dtype=ids.dtype), ids[1:]], dim=1)
+        pmask = torch.ones_like(pad_ids, dtype=torch.bool)
+        pmask[:, :5] = False
+        c = model.generate(pad_ids, seqs[1:], attention_mask=pmask, max_new_tokens=8, pad_token_id=0)
+        assert torch.equal(c[0, :4], a[1, :4])
+    finally:
+        del model
+        torch.cuda.empty_cache()
