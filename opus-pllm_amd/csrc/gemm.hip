@@ -1235,8 +1235,7 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
     const bool skinny = p.M <= SKINNY_MAX_M;
     static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;   // A/B aid
     const bool mid = !skinny && p.M <= MID_MAX_M && !no_mid;
-    static const bool mid_v1 = getenv("OPUS_MID_V1") != nullptr;
-    static const int ring_mid = getenv("OPUS_RING_MID") ? atoi(getenv("OPUS_RING_MID")) : 0;        // A/B aid: 4-panel kernel for every mid shape
+    static const bool mid_v1 = getenv("OPUS_MID_V1") != nullptr;        // A/B aid: 4-panel kernel for every mid shape
     if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;
     if (p.Af && !skinny && !mid) return hipErrorInvalidValue;   // fused norm: skinny and mid kernels only
     if (p.Af && p.epi == EPI_GELU) return hipErrorInvalidValue;
