@@ -265,7 +265,12 @@ class OpusLlamaForCausalLM:
         mask = mask.to(torch.uint8).contiguous()
         s = self._enter()
         with torch.cuda.stream(self._stream):
-            out = torch.full((B, max_new), pad_id, dtype=torch.int32, device=self.device)
+            # one persistent id buffer: its address is part of the captured decode graph's identity
+            if getattr(self, "_out_ids", None) is None or self._out_ids.shape[0] < B or self._out_ids.shape[1] < max_new:
+                self._out_ids = torch.empty((max(B, self.cfg.max_batch), max(max_new, self.cfg.max_new_tokens)),
+                                            dtype=torch.int32, device=self.device)
+            out = self._out_ids.view(-1)[: B * max_new].view(B, max_new)
+            out.fill_(pad_id)
             n_out = C.c_int32(0)
             eos_arr = (C.c_int32 * max(1, len(eos)))(*eos)
             if sampler is None:
@@ -276,7 +281,7 @@ class OpusLlamaForCausalLM:
                                                            eos_arr, len(eos), pad_id, sampler[0], sampler[1], sampler[2],
                                                            out.data_ptr(), C.byref(n_out), s))
         self._leave()
-        return out[:, : n_out.value].long()
+        return out[:, : n_out.value].long()              # (a copy: the id buffer is reused by the next call)
 
     def generate_from_tokens(self, d_tokens, d_lens, input_ids: torch.Tensor,
                              attention_mask: Optional[torch.Tensor], max_new_tokens: int, eos: Sequence[int] = (),
