@@ -902,6 +902,200 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pp: 256 x 256 x 64 tile, 8 waves as 2 wave-rows x 4 wave-columns (128 x 64 outputs per wave), the two wave-rows run
+// half a phase apart ("ping-pong"): every phase is  [fragment reads + 2 LDS-DMA requests + counted vmcnt] barrier
+// [16 MFMAs at raised priority] barrier, and wave-row 1 starts one barrier late, so on every SIMD (waves w and w+4) one
+// wave is in its MFMA cluster while the other reads LDS and issues DMA - neither waits behind the other's issue stalls.
+// (cdna_hip_programming.md "The 256^2 8-phase template": same geometry, schedule re-derived here.)
+//
+// One K-tile of 64 = four phases = the four 64 x 32 quadrants of the wave's output in snake order
+//   (rows 0-63, cols 0-31) -> (rows 0-63, cols 32-63) -> (rows 64-127, cols 32-63) -> (rows 64-127, cols 0-31)
+// so a phase needs at most one new operand set: A rows-lo + B cols-lo, then B cols-hi, then A rows-hi, then nothing.
+// The tile's operands therefore arrive as four 16-KB "half-tiles" in that order of need
+//   H0 = A rows {0-63, 128-191}   H1 = B cols-lo of the 4 wave-columns   H2 = B cols-hi   H3 = A rows {64-127, 192-255}
+// in 8 LDS slots (two K-tiles); half-tile h is requested in phase h-4 and first read in phase h - {0,1,1,1}, i.e. at
+// least 3 phases later; its slot was last read >= 2 phases (4 barriers) before the request.  RAW: the reader passes a
+// barrier after every wave's counted vmcnt (one phase later, both wave-rows); WAR: see above.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HT = 16384;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+    int bid = blockIdx.x;
+    {   // XCD-aware order, as the ring kernel
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int grp = bid / per_group, rem_id = bid - grp * per_group;
+    const int rows_here = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;
+    const int tm = grp * GM + rem_id % rows_here, tn = rem_id / rows_here;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int KT = p.K >> 6, NH = 4 * KT;
+    const int npanels = (p.N + 15) >> 4;
+
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    // DMA sources of this wave's two 1-KB pieces (q = 2 wave + j) of each kind of half-tile
+    const half_t *srcA[2][2], *srcB[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = 2 * wave + j;
+        const int lr = 8 * q + (lane >> 3);                           // row inside the half-tile image
+        const int chunk = (lane & 7) ^ ((lr >> 1) & 7);               // swizzle goes on the source address
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            int row = m0 + (lr >> 6) * 128 + rh * 64 + (lr & 63);
+            row = row < p.M ? row : p.M - 1;
+            srcA[j][rh] = p.A + (int64_t)row * p.lda + chunk * 8;
+        }
+        const int pi = q >> 1, s = q & 1;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            int pn = (n0 >> 4) + (pi >> 1) * 4 + ch * 2 + (pi & 1);
+            pn = pn < npanels ? pn : npanels - 1;
+            srcB[j][ch] = p.W + ((int64_t)pn * KT) * 1024 + s * 512 + lane * 8;
+        }
+    }
+    auto issue_half = [&](int hq) {
+        const int kt = hq >> 2, i = hq & 3;
+        char *dst = smem + (hq & 7) * HT + (2 * wave) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const half_t *src = (i == 0 || i == 3) ? srcA[j][i == 3] + (int64_t)kt * 64 : srcB[j][i == 2] + (int64_t)kt * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    h8 af[4][2], b0[2][2], b1[2][2];
+    int aoff[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int lr = wr * 64 + rt * 16 + li;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) aoff[rt][s] = lr * 128 + (((4 * s + g) ^ ((lr >> 1) & 7)) << 4);
+    }
+    const int boff = (wc * 2) * 2048 + lane * 16;
+    auto read_a = [&](int kt, int rh) {
+        const char *base = smem + (4 * (kt & 1) + (rh ? 3 : 0)) * HT;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) af[rt][s] = *reinterpret_cast<const h8 *>(base + aoff[rt][s]);
+    };
+    auto read_b = [&](int kt, int ch, h8 (&bf)[2][2]) {
+        const char *base = smem + (4 * (kt & 1) + 1 + ch) * HT + boff;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bf[ct][s] = *reinterpret_cast<const h8 *>(base + ct * 2048 + s * 1024);
+    };
+    auto mfma_quadrant = [&](int rh, int ch, const h8 (&bf)[2][2]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int rhh = 0; rhh < 2; ++rhh)
+#pragma unroll
+                        for (int chh = 0; chh < 2; ++chh)
+                            if (rhh == rh && chh == ch)
+                                acc[4 * rhh + rt][2 * chh + ct] =
+                                    __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ct][s], af[rt][s], acc[4 * rhh + rt][2 * chh + ct], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // end of a phase's load section: request half-tile phi+4, then retire everything up to half-tile phi+2
+    auto feed = [&](int phi) {
+        if (phi + 4 < NH) {
+            issue_half(phi + 4);
+            vmcnt_wait<4>();
+        } else if (phi + 3 < NH) {
+            vmcnt_wait<2>();
+        } else {
+            vmcnt_wait<0>();
+        }
+    };
+
+    // prologue: the first K-tile's four half-tiles
+#pragma unroll
+    for (int h = 0; h < 4; ++h) issue_half(h);
+    vmcnt_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                        // wave-row 1 runs one barrier behind
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int phi = 4 * kt;
+        // phase 0: rows-lo x cols-lo
+        read_b(kt, 0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(kt, 0);
+        feed(phi);
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(0, 0, b0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1: rows-lo x cols-hi
+        read_b(kt, 1, b1);
+        feed(phi + 1);
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(0, 1, b1);
+        __builtin_amdgcn_s_barrier();
+        // phase 2: rows-hi x cols-hi
+        read_a(kt, 1);
+        feed(phi + 2);
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(1, 1, b1);
+        __builtin_amdgcn_s_barrier();
+        // phase 3: rows-hi x cols-lo (operands already in registers)
+        feed(phi + 3);
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(1, 0, b0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                        // every wave executes the same number of barriers
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + li;
+        if (m >= p.M) continue;
+        if (EPI == EPI_SILU_GU16) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wc * 64 + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wc * 64 + j * 16 + 4 * g, acc[i][j], acc[i][j]);
+        }
+    }
+}
+
+template <int EPI>
+static hipError_t launch_pp(const GemmParams &p, hipStream_t s) {
+    const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pp_kernel<EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        if (ea != hipSuccess) return ea;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(bm * bn), dim3(512), 8 * 16384, s, p, bm, bn);
+    return hipGetLastError();
+}
+
 // out[m][no] = epi(sum_ks slab[ks][m][n] + bias) (+ residual): one thread per output element.
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ksplit) {
@@ -1204,11 +1398,15 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     }
     static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr;   // A/B aid
     if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) {   // enough 256 x 256 tiles to fill the chip
-        // short reductions with a heavy epilogue (fp32 residual read-modify-write, GELU): 128 x 128 tiles, two workgroups
-        // per CU, so one workgroup's epilogue runs under the other's MFMAs (+8..20 % on the ESM wo / fc1 and decoder wo
-        // shapes; long-K and plain-store shapes measured faster on the 256 x 256 tile)
-        if ((p.residual || EPI == EPI_GELU) && p.K <= 4096) return launch_ring<4, 2, 4, EPI>(p, s, false);
-        return launch_ring<8, 4, 4, EPI>(p, s, false);
+        static const bool no_pp = getenv("OPUS_NO_PP") != nullptr;          // A/B aid: single-phase ring kernels instead
+        if (no_pp) {
+            if ((p.residual || EPI == EPI_GELU) && p.K <= 4096) return launch_ring<4, 2, 4, EPI>(p, s, false);
+            return launch_ring<8, 4, 4, EPI>(p, s, false);
+        }
+        // short reduction + fp32 residual read-modify-write (ESM wo): 128 x 128 tiles, two workgroups per CU, one's
+        // epilogue under the other's MFMAs (196 vs 222 us); everything else: the ping-pong 256 x 256 x 64 kernel
+        if (p.residual && p.K <= 2048) return launch_ring<4, 2, 4, EPI>(p, s, false);
+        return launch_pp<EPI>(p, s);
     }
     // Too few output tiles to fill 256 CUs (B = 1 prefill, single-protein encoder): split K so that
     // ~256-320 workgroups stream the weights, at least 4 k-tiles each, slabs within the workspace.
