@@ -917,6 +917,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_
 // in 8 LDS slots (two K-tiles); half-tile h is requested in phase h-4 and first read in phase h - {0,1,1,1}, i.e. at
 // least 3 phases later; its slot was last read >= 2 phases (4 barriers) before the request.  RAW: the reader passes a
 // barrier after every wave's counted vmcnt (one phase later, both wave-rows); WAR: see above.
+constexpr int PP_DIST = 6;   // half-tiles requested ahead (4..6)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    h8 af[4][2], b0[2][2], b1[2][2];
+    h8 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
     int aoff[4][2];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         for (int s = 0; s < 2; ++s) aoff[rt][s] = lr * 128 + (((4 * s + g) ^ ((lr >> 1) & 7)) << 4);
     }
     const int boff = (wc * 2) * 2048 + lane * 16;
-    auto read_a = [&](int kt, int rh) {
+    auto read_a = [&](int kt, int rh, h8 (&af)[4][2]) {
         const char *base = smem + (4 * (kt & 1) + (rh ? 3 : 0)) * HT;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
 #pragma unroll
             for (int s = 0; s < 2; ++s) bf[ct][s] = *reinterpret_cast<const h8 *>(base + ct * 2048 + s * 1024);
     };
-    auto mfma_quadrant = [&](int rh, int ch, const h8 (&bf)[2][2]) {
+    auto mfma_quadrant = [&](int rh, int ch, const h8 (&af)[4][2], const h8 (&bf)[2][2]) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1019,51 +1020,57 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                 }
         __builtin_amdgcn_s_setprio(0);
     };
-    // end of a phase's load section: request half-tile phi+4, then retire everything up to half-tile phi+2
+    // end of a phase's load section: request half-tile phi+D, then retire everything up to half-tile phi+2 (the reads of
+    // phase phi+1).  D <= 6: the slot of phi+D last held phi+D-8, read no later than phase phi+D-8, i.e. >= 2 phases ago.
+    constexpr int D = PP_DIST;
     auto feed = [&](int phi) {
-        if (phi + 4 < NH) {
-            issue_half(phi + 4);
-            vmcnt_wait<4>();
-        } else if (phi + 3 < NH) {
-            vmcnt_wait<2>();
+        if (phi + D < NH) {
+            issue_half(phi + D);
+            vmcnt_wait<2 * (D - 2)>();
         } else {
-            vmcnt_wait<0>();
+            const int left = NH - 1 - (phi + 2);                      // half-tiles issued beyond phi+2 (tail)
+            if (left >= 3) vmcnt_wait<6>();
+            else if (left == 2) vmcnt_wait<4>();
+            else if (left == 1) vmcnt_wait<2>();
+            else vmcnt_wait<0>();
         }
     };
 
-    // prologue: the first K-tile's four half-tiles
+    // prologue: the first D half-tiles; K-tile 0 (half-tiles 0..3) must have landed
 #pragma unroll
-    for (int h = 0; h < 4; ++h) issue_half(h);
-    vmcnt_wait<0>();
+    for (int h = 0; h < D; ++h)
+        if (h < NH) issue_half(h);
+    if (NH >= D) vmcnt_wait<2 * (D - 4)>();
+    else vmcnt_wait<0>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                        // wave-row 1 runs one barrier behind
+    read_a(0, 0, a0);
 
     for (int kt = 0; kt < KT; ++kt) {
         const int phi = 4 * kt;
-        // phase 0: rows-lo x cols-lo
+        // phase 0: rows-lo x cols-lo   (rows-lo fragments were read in the previous phase 3 / the prologue)
         read_b(kt, 0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(kt, 0);
         feed(phi);
         __builtin_amdgcn_s_barrier();
-        mfma_quadrant(0, 0, b0);
+        mfma_quadrant(0, 0, a0, b0);
         __builtin_amdgcn_s_barrier();
         // phase 1: rows-lo x cols-hi
         read_b(kt, 1, b1);
         feed(phi + 1);
         __builtin_amdgcn_s_barrier();
-        mfma_quadrant(0, 1, b1);
+        mfma_quadrant(0, 1, a0, b1);
         __builtin_amdgcn_s_barrier();
         // phase 2: rows-hi x cols-hi
-        read_a(kt, 1);
+        read_a(kt, 1, a1);
         feed(phi + 2);
         __builtin_amdgcn_s_barrier();
-        mfma_quadrant(1, 1, b1);
+        mfma_quadrant(1, 1, a1, b1);
         __builtin_amdgcn_s_barrier();
-        // phase 3: rows-hi x cols-lo (operands already in registers)
+        // phase 3: rows-hi x cols-lo; its load section fetches the next K-tile's rows-lo fragments
+        if (kt + 1 < KT) read_a(kt + 1, 0, a0);
         feed(phi + 3);
         __builtin_amdgcn_s_barrier();
-        mfma_quadrant(1, 0, b0);
+        mfma_quadrant(1, 0, a1, b0);
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                        // every wave executes the same number of barriers
