@@ -1075,17 +1075,102 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                        // every wave executes the same number of barriers
 
+    // ---- epilogue ----
+    // The accumulators hold 4 consecutive columns of 16 different rows per lane group: stored directly, a wave-wide
+    // store touches 16 rows x 32-B pieces.  The LDS is idle now, so each wave turns its 16-row x 64-column slabs
+    // through a private LDS patch and writes / reads-modifies-writes whole 16-B-per-lane row segments instead.
+    constexpr int NO = EPI == EPI_SILU_GU16 ? 32 : 64;                 // output columns per wave
+    const int nlim = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
+    const int nw0 = EPI == EPI_SILU_GU16 ? (n0 >> 1) + wc * 32 : n0 + wc * 64;   // first output column of this wave
+    const bool rows16 = ((p.ldc & 7) == 0) && ((p.ldr & 3) == 0) && nw0 + NO <= nlim;
+    if (!rows16) {                                                    // ragged right edge / odd strides: element-wise path
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + li;
+            if (m >= p.M) continue;
+            if (EPI == EPI_SILU_GU16) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wc * 64 + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wc * 64 + j * 16 + 4 * g, acc[i][j], acc[i][j]);
+            }
+        }
+        return;
+    }
+    float *patch = reinterpret_cast<float *>(smem + wave * 16384);     // [16 rows][NO + 4] fp32
+    constexpr int PS = NO + 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + li;
-        if (m >= p.M) continue;
+        // 1. bias / activation in registers, 4 columns per lane -> patch[li][...]
         if (EPI == EPI_SILU_GU16) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wc * 64 + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
+            for (int jj = 0; jj < 2; ++jj) {
+                const int nb = n0 + wc * 64 + jj * 32 + 4 * g;        // gate columns in the GEMM's N space
+                f4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float gate = acc[i][2 * jj][r], up = acc[i][2 * jj + 1][r];
+                    if (p.bias) { gate += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
+                    v[r] = silu(gate) * up;
+                }
+                *reinterpret_cast<f4 *>(patch + li * PS + jj * 16 + 4 * g) = v;
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wc * 64 + j * 16 + 4 * g, acc[i][j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) {
+                const int nb = n0 + wc * 64 + j * 16 + 4 * g;
+                f4 v = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (p.bias) v[r] += p.bias[nb + r];
+                    if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
+                }
+                *reinterpret_cast<f4 *>(patch + li * PS + j * 16 + 4 * g) = v;
+            }
         }
+        // same-wave LDS round trip (in-order LDS queue); the fences keep the compiler from reordering across it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 2. row segments: lane -> (row, 4- or 8-column piece)
+        const int mrow0 = m0 + wr * 128 + i * 16;
+        if (p.out_f32) {
+            constexpr int LPR = NO / 4, RPP = 64 / LPR;               // lanes per row, rows per pass
+#pragma unroll
+            for (int ps = 0; ps < 16 / RPP; ++ps) {
+                const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 4;
+                const int m = mrow0 + r;
+                f4 v = *reinterpret_cast<const f4 *>(patch + r * PS + c);
+                if (m < p.M) {
+                    if (p.residual) {
+                        const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    }
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + nw0 + c) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        } else {
+            constexpr int LPR = NO / 8, RPP = 64 / LPR;
+#pragma unroll
+            for (int ps = 0; ps < 16 / RPP; ++ps) {
+                const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 8;
+                const int m = mrow0 + r;
+                f4 lo = *reinterpret_cast<const f4 *>(patch + r * PS + c), hi = *reinterpret_cast<const f4 *>(patch + r * PS + c + 4);
+                if (m < p.M) {
+                    if (p.residual) {
+                        const float4 r0 = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
+                        const float4 r1 = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c + 4);
+                        lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
+                        hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
+                    }
+                    *reinterpret_cast<h8 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c) =
+                        h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+                }
+            }
+        }
+        // the patch is rewritten by the next row tile: its reads above must have retired (same wave, in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -1410,9 +1495,6 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
             if ((p.residual || EPI == EPI_GELU) && p.K <= 4096) return launch_ring<4, 2, 4, EPI>(p, s, false);
             return launch_ring<8, 4, 4, EPI>(p, s, false);
         }
-        // short reduction + fp32 residual read-modify-write (ESM wo): 128 x 128 tiles, two workgroups per CU, one's
-        // epilogue under the other's MFMAs (196 vs 222 us); everything else: the ping-pong 256 x 256 x 64 kernel
-        if (p.residual && p.K <= 2048) return launch_ring<4, 2, 4, EPI>(p, s, false);
         return launch_pp<EPI>(p, s);
     }
     // Too few output tiles to fill 256 CUs (B = 1 prefill, single-protein encoder): split K so that
