@@ -80,7 +80,7 @@ def test_synthetic_fill_matches_numpy_twin(dev):
     (48, 4096, 4096, 0, 1, True), (96, 6144, 4096, 0, 0, False), (128, 1056, 1280, 1, 0, False), (70, 4096, 14336, 0, 1, True),
     (65, 128, 64, 0, 0, False), (130, 384, 320, 1, 0, False), (257, 200, 128, 0, 1, True), (300, 512, 1280, 2, 0, False),
     (514, 3840, 1280, 0, 0, False), (1, 32768, 5120, 1, 0, False),
-    # >= 192 tiles of 256 x 256: the 8-wave LDS-DMA pipelined kernel (ragged M/N, 2 / 4 / 10 / 20 K stages)
+    # >= 192 tiles of 256 x 256: the ping-pong 256 x 256 x 64 kernel (ragged M/N; 5, 1, 2, 10 K-tiles: prologue / tail paths)
     (4100, 3000, 320, 1, 0, False), (3000, 4100, 64, 0, 1, True), (2600, 5120, 128, 2, 0, False), (3900, 3328, 640, 0, 0, False),
 ])
 def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
@@ -190,6 +190,34 @@ def test_attention_kernel(micro, dev, B, T, heads, group, hd, causal):
     err = ((o - ref).abs() * rows_ok[..., None]).max().item()
     assert err <= 4e-3, err
     assert float(o[~rows_ok].abs().max() if (~rows_ok).any() else 0.0) == 0.0   # fully masked rows -> zeros
+
+
+def test_pingpong_gemm_repeats_bit_identically(micro, dev):
+    """Race screen for gemm_pp_kernel (LDS-DMA half-tiles ordered only by counted vmcnt + barriers): repeated launches
+    of the same problem must agree bit for bit, and with an fp64 reference within the kernel tolerance."""
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model, _ = micro
+    for (M, N, K, epi) in [(4352, 4352, 1280, 0), (3000, 8192, 448, 2)]:
+        g = torch.Generator().manual_seed(K)
+        A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+        dW = tile_weight(W)
+        nout = N // 2 if epi == 2 else N
+        outs = []
+        for _ in range(6):
+            out = torch.zeros(M, nout, dtype=torch.float16, device=dev)
+            _cabi.check(_cabi.lib().opus_debug_gemm(model._ctx, A.data_ptr(), dW.data_ptr(), None, None, out.data_ptr(), M, N, K,
+                                                    epi, 0, None))
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        ref = A.double() @ W.double().T
+        if epi == 2:
+            ref = ref.view(M, N // 32, 2, 16)
+            ref = (torch.nn.functional.silu(ref[:, :, 0]) * ref[:, :, 1]).reshape(M, nout)
+        err = (outs[0].double() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-5, err
 
 
 # ------------------------------------------------------------------------------------------------ path vs goldens

@@ -43,3 +43,21 @@ for (M, N, K, epi, f32, res) in [(4096, 4096, 1024, 0, 0, 0), (4100, 3968, 192, 
     print(f"M={M} N={N} K={K} epi={epi} f32={f32} res={res}: rel max err {err:.2e}", flush=True)
 assert worst < 2e-3, worst
 print("ok")
+
+# race screen: the same GEMM launched repeatedly must give bit-identical results (a DMA / barrier race would show as
+# occasional differing tiles); mixed shapes exercise the prologue, tail and ragged-edge paths
+for (M, N, K, epi, f32) in [(8192, 8192, 1280, 0, 0), (32896, 1280, 1280, 0, 1), (6144, 28672, 4096, 2, 0), (4100, 4128, 320, 1, 0)]:
+    A = torch.randn(M, K, device=dev).half()
+    Np = (N + 15) // 16 * 16
+    Wt = tile_weight((torch.randn(Np, K, device=dev) * 0.05).half().contiguous())
+    nout = N // 2 if epi == 2 else N
+    outs = []
+    for it in range(12):
+        out = torch.zeros(M, nout, dtype=torch.float32 if f32 else torch.float16, device=dev)
+        _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), Wt.data_ptr(), None, None, out.data_ptr(), M, N, K, epi, f32, None))
+        outs.append(out)
+    torch.cuda.synchronize()
+    same = all(torch.equal(outs[0], o) for o in outs[1:])
+    print(f"repeat M={M} N={N} K={K} epi={epi}: {'identical' if same else 'DIFFERENT'} over {len(outs)} launches", flush=True)
+    assert same
+print("race screen ok")
