@@ -1489,7 +1489,8 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
         attr_set = true;
     }
     static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr;   // A/B aid
-    if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 192) {   // enough 256 x 256 tiles to fill the chip
+    static const int min_tiles = getenv("OPUS_PP_MIN_TILES") ? atoi(getenv("OPUS_PP_MIN_TILES")) : 128;   // tuning aid (pp wins from about half a chip of tiles)
+    if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= min_tiles) {   // enough 256 x 256 tiles to fill the chip
         static const bool no_pp = getenv("OPUS_NO_PP") != nullptr;          // A/B aid: single-phase ring kernels instead
         if (no_pp) {
             if ((p.residual || EPI == EPI_GELU) && p.K <= 4096) return launch_ring<4, 2, 4, EPI>(p, s, false);

@@ -92,7 +92,7 @@ if __name__ == "__main__":
         bench_tile("square 8192", 8192, 8192, 8192, 0)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "m96":
-        for M in (96, 128, 514, 1028):
+        for M in (96, 128, 514, 1028, 2056, 4112, 8224):
             if M <= 128:
                 bench_tile("dec qkv", M, 6144, 4096, 0)
                 bench_tile("dec wo +res", M, 4096, 4096, 0, True, True)
