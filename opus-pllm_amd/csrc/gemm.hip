@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
     f4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
+    constexpr int U = 4;                                            // weight ring: 4 chunks = 8 KB per wave (8 measured slower)
     h8 wl[U], wh[U];
     auto w_load = [&](int u, int c) {
         if (c < c1) {
@@ -1307,15 +1307,66 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
     }
 
     dma_stage(0, c0);
+    // The weight ring is loaded with inline asm and waited for with hand-counted vmcnt: the compiler's waitcnt pass does not
+    // count across a mix of LDS-DMA and register loads and would put vmcnt(0) - a full drain, DMA included - in front
+    // of each stage's first MFMA.  The waits take the registers as in/out operands so that no MFMA can move above them.
+    auto ld_nt = [&](h8 &lo, h8 &hi, const half_t *ptr) {
+        asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %2, off offset:1024 nt"
+                     : "=&v"(lo), "=&v"(hi) : "v"(ptr));            // (read-only weights: no memory clobber, so the
+    };                                                                  //  LDS fragment reads can be scheduled around it)
 #pragma unroll
-    for (int u = 0; u < U; ++u) w_load(u, c0 + u);
-    int buf = 0;
-    for (int cs = c0; cs < c1; cs += SC, buf ^= 1) {
-        // the DMA of this stage was issued before the (at most) 8 weight loads still in flight
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int u = 0; u < U; ++u) {
+        const int cn = c0 + u < c1 ? c0 + u : c1 - 1;
+        ld_nt(wl[u], wh[u], wp + (int64_t)cn * 1024);
+    }
+    int buf = 0, cs = c0;
+    // steady state: this stage is full and another one follows -> a branch-free body (DMA of the next stage, 8 x
+    // [MFMAs, clamped refill]).  With conditional loads or a conditional DMA the compiler cannot count what is in flight
+    // and drains the whole queue - the just-issued DMA included - in front of the stage's first MFMA.
+    for (; cs + SC < c1; cs += SC, buf ^= 1) {
+        // the DMA of this stage was issued before the (at most) 2 U weight loads still in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * U) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's fragment reads of the other buffer
         __builtin_amdgcn_s_barrier();
-        if (cs + SC < c1) dma_stage(buf ^ 1, cs + SC);
+        dma_stage(buf ^ 1, cs + SC);
+        const char *base = smem + buf * STAGE;
+        // activation fragments of chunk u8+1 are read while chunk u8 is multiplied (two register sets, static parity)
+        h8 fa[2][MT][2];
+        auto read_chunk = [&](int u8, h8 (&f)[MT][2]) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f[i][0] = *reinterpret_cast<const h8 *>(base + u8 * CIMG + aoff[i]);
+                f[i][1] = *reinterpret_cast<const h8 *>(base + u8 * CIMG + (aoff[i] ^ 64));
+            }
+        };
+        read_chunk(0, fa[0]);
+#pragma unroll
+        for (int u8 = 0; u8 < SC; ++u8) {
+            const int c = cs + u8;
+            const int u = u8 & (U - 1);
+            if (u8 + 1 < SC) read_chunk(u8 + 1, fa[(u8 + 1) & 1]);
+            // younger than this chunk's pair (requested U chunks ago): the U-1 later refills, plus this stage's PW DMA
+            // requests when the pair was requested before them (first U chunks of the stage)
+            if (u8 < U) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wl[u]), "+v"(wh[u]) : "n"(2 * (U - 1) + PW));
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wl[u]), "+v"(wh[u]) : "n"(2 * (U - 1)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], fa[u8 & 1][i][0], acc[i], 0, 0, 0);   // C^T tile
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], fa[u8 & 1][i][1], acc[i], 0, 0, 0);
+            }
+            const int cn = c + U < c1 ? c + U : c1 - 1;              // (clamped: a few redundant loads at the very end)
+            // the refill overwrites registers the MFMAs above read: in/out operands order it behind them
+            asm volatile("" : "+v"(wl[u]), "+v"(wh[u]));
+            ld_nt(wl[u], wh[u], wp + (int64_t)cn * 1024);
+        }
+    }
+    {   // last stage (possibly partial): guarded, everything in flight is retired first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wl[u]), "+v"(wh[u]));
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         const char *base = smem + buf * STAGE;
 #pragma unroll
         for (int u8 = 0; u8 < SC; ++u8) {

@@ -80,6 +80,8 @@ def test_synthetic_fill_matches_numpy_twin(dev):
     (48, 4096, 4096, 0, 1, True), (96, 6144, 4096, 0, 0, False), (128, 1056, 1280, 1, 0, False), (70, 4096, 14336, 0, 1, True),
     (65, 128, 64, 0, 0, False), (130, 384, 320, 1, 0, False), (257, 200, 128, 0, 1, True), (300, 512, 1280, 2, 0, False),
     (514, 3840, 1280, 0, 0, False), (1, 32768, 5120, 1, 0, False),
+    # wide outputs at 17..96 rows: the 8-panel stream kernel with 2 / 4 / 6 row tiles, full and partial last stage
+    (24, 16384, 1024, 0, 0, False), (32, 16416, 4096, 2, 0, False), (64, 20480, 1088, 1, 0, False), (90, 16384, 576, 2, 0, False),
     # >= 192 tiles of 256 x 256: the ping-pong 256 x 256 x 64 kernel (ragged M/N; 5, 1, 2, 10 K-tiles: prologue / tail paths)
     (4100, 3000, 320, 1, 0, False), (3000, 4100, 64, 0, 1, True), (2600, 5120, 128, 2, 0, False), (3900, 3328, 640, 0, 0, False),
 ])
