@@ -102,6 +102,13 @@ struct opus_ctx {
     unsigned *d_bar = nullptr;
     unsigned long long *d_trace = nullptr;
     bool stack_used = false, g_stack = false;
+    // row-scale fusion (GemmParams::xh_out / row_ssq): one-shot request for the next gemm() and its outcome
+    half_t *rq_xh = nullptr;
+    int rq_done = 0;
+    const float *xh_src = nullptr;       // fp32 buffer whose fp16 copy + sum-of-squares partials are valid
+    bool use_row_scale = false;          // one-shot: the next gemm() multiplies its rows by the rstd from d_ssq
+    float *d_ssq = nullptr;
+    float row_eps = 0.f;
     // timing
     bool timing = false;
     std::vector<TimeRec> recs;
@@ -175,6 +182,7 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->gemm_ws_bytes = 64ll << 20;   // split-K slabs of the tile GEMM
     c->gemm_ws = k.take<float>((size_t)c->gemm_ws_bytes / sizeof(float));
     c->d_pidx = k.take<int32_t>(64 * B);
+    c->d_ssq = k.take<float>(128 * 32);
     *total = k.off;
 }
 
@@ -427,6 +435,11 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     p.residual = residual; p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
     p.ws = c->gemm_ws; p.ws_bytes = c->gemm_ws_bytes;
     p.ev0 = p.ev1 = nullptr;
+    p.xh_out = c->rq_xh; p.ssq_out = c->d_ssq; p.fused_done = &c->rq_done;
+    c->rq_done = 0;
+    c->rq_xh = nullptr;                  // one-shot
+    p.row_ssq = nullptr; p.row_nblk = 0;
+    if (c->use_row_scale) { p.row_ssq = c->d_ssq; p.row_nblk = K >> 8; p.norm_eps = c->row_eps; c->use_row_scale = false; }
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
                          (residual ? 4.0 * M * nout : 0.0);
@@ -449,6 +462,10 @@ static int gemm(opus_ctx *c, hipStream_t s, const half_t *A, int64_t lda, const 
                 const float *bias, int epi, const float *residual, void *C, int64_t ldc, int out_f32) {
     return gemm_any(c, s, A, nullptr, 0.f, lda, W, M, N, K, bias, epi, residual, C, ldc, out_f32);
 }
+static bool fuse_rows() {
+    static const bool off = getenv("OPUS_NO_ROW_FUSION") != nullptr;   // A/B aid
+    return !off;
+}
 #define KL(klass, bytes, call)                                                                        \
     do {                                                                                              \
         Timed t_(c, s, klass, bytes);                                                                 \
@@ -462,6 +479,15 @@ static int gemm_norm(opus_ctx *c, hipStream_t s, const float *X, float eps, half
                      int K, int epi, void *C, int64_t ldc, int out_f32, const float *bias = nullptr) {
     static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;
     static const bool mid_v1 = getenv("OPUS_MID_V1") != nullptr;
+    if (c->xh_src == X && bias == nullptr && (K & 255) == 0 && gemm_goes_wide(M, N)) {
+        // the producer's split-K reduce left fp16(X) in `scratch` and per-block sums of squares: no norm launch, the
+        // wide kernel scales its rows instead
+        c->xh_src = nullptr;
+        c->use_row_scale = true;
+        c->row_eps = eps;
+        return gemm(c, s, scratch, K, W, M, N, K, nullptr, epi, nullptr, C, ldc, out_f32);
+    }
+    c->xh_src = nullptr;
     // 17..64 rows with a wide output (wgu, lm_head): the wide kernel wants fp16 activations, so norm separately
     const bool wide = M > SKINNY_MAX_M && N >= 16384 && !mid_v1;
     if (M <= SKINNY_MAX_M || (M <= MID_MAX_M && !no_mid && !wide))
@@ -718,7 +744,9 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
         a.B = B; a.T = T; a.heads = nh; a.group = nh / nkv; a.head_dim = hd; a.causal = 1;
         a.scale = 1.0f / sqrtf((float)hd);
         KL(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), launch_attn_prefill(a, s));
+        if (fuse_rows() && M <= 96) c->rq_xh = c->d_xn;      // (d_ssq holds 128 rows)
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
+        c->xh_src = c->rq_done ? c->d_x : nullptr;
         OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wgu, M, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
         OPC(gemm(c, s, c->d_act, F, L.wd, M, H, F, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
     }
@@ -797,7 +825,9 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
            launch_attn_decode(c->d_qkv, c->cs_dec, c->d_kstart, c->d_step, T, B, nh, nkv, hd, c->kc + l * c->cache_sl,
                               c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, ctx_cap, 1.0f / sqrtf((float)hd),
                               c->d_ctx, s));
+        if (fuse_rows() && B <= 96) c->rq_xh = c->d_xln;
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, B, H, QD, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
+        c->xh_src = c->rq_done ? c->d_xl : nullptr;
         OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wgu, B, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
         OPC(gemm(c, s, c->d_act, F, L.wd, B, H, F, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
     }

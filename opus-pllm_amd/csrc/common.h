@@ -37,6 +37,15 @@ struct GemmParams {
     int epi;
     float *ws;              // split-K workspace (fp32 partial slabs) or nullptr
     int64_t ws_bytes;
+    // Row-scale fusion (RMSNorm between a split-K GEMM and the wide kernel that consumes its output):
+    //  producer side - the flat split-K reduce (EPI_NONE, fp32 output, N % 256 == 0) also writes the row as fp16 to xh_out
+    //  and the sum of squares of each 256-column block to ssq_out[m * N/256 + j], then sets *fused_done;
+    //  consumer side - gemm_wide_kernel multiplies row m of its result by rsqrt(sum_j row_ssq[m * row_nblk + j] / K + norm_eps).
+    half_t *xh_out;
+    float *ssq_out;
+    int *fused_done;
+    const float *row_ssq;
+    int row_nblk;
     // measurement: when set, the skinny kernel is dispatched with hipExtLaunchKernelGGL so that these events
     // carry the dispatch's own start / end timestamps (what rocprofv3 reports), not a bracket around it
     hipEvent_t ev0, ev1;
@@ -57,6 +66,7 @@ struct AttnParams {
 };
 
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass);
+bool gemm_goes_wide(int M, int N);   // would launch_gemm route an fp16-A GEMM of this shape to gemm_wide_kernel?
 hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s);
 
 // norm.hip

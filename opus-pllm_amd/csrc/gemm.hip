@@ -1224,12 +1224,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
     if (p.residual) v += p.residual[(int64_t)m * p.ldr + no];
     if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
     else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
+    if (EPI == EPI_NONE && p.xh_out) {   // (host guarantees N % 256 == 0: the workgroup lies inside one row, no early return above)
+        p.xh_out[(int64_t)m * p.N + no] = (half_t)v;
+        __shared__ float part[4];
+        float q = v * v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) p.ssq_out[(int64_t)m * (p.N >> 8) + (no >> 8)] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
 }
 
 template <int EPI>
 static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s) {
     const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, p, ks);
+    GemmParams q = p;
+    if (EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 && !p.Af && (p.N & 255) == 0) *p.fused_done = 1;
+    else q.xh_out = nullptr;
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, q, ks);
     return hipGetLastError();
 }
 
@@ -1306,6 +1319,23 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
         aoff[i] = r * 128 + ((g ^ ((r >> 1) & 7)) << 4);             // second k-step: ^ (4 << 4) on the chunk index
     }
 
+    // row sums of squares for the fused RMSNorm (GemmParams::row_ssq): requested up front, used in the epilogue
+    float rssq[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rssq[i] = 0.f;
+    if (p.row_ssq) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int m = 16 * i + li;
+            m = m < p.M ? m : p.M - 1;
+            const float *src = p.row_ssq + m * p.row_nblk;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int j = 0;
+            for (; j + 4 <= p.row_nblk; j += 4) { s0 += src[j]; s1 += src[j + 1]; s2 += src[j + 2]; s3 += src[j + 3]; }
+            for (; j < p.row_nblk; ++j) s0 += src[j];
+            rssq[i] = (s0 + s1) + (s2 + s3);
+        }
+    }
     dma_stage(0, c0);
     // The weight ring is loaded with inline asm and waited for with hand-counted vmcnt: the compiler's waitcnt pass does not
     // count across a mix of LDS-DMA and register loads and would put vmcnt(0) - a full drain, DMA included - in front
@@ -1400,6 +1430,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
         }
         return;
     }
+    if (p.row_ssq) {   // RMSNorm of the activation rows, applied to the (linear) result: see GemmParams::row_ssq
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float rs = rsqrtf(rssq[i] / (float)p.K + p.norm_eps);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] *= rs;
+        }
+    }
     if (EPI == EPI_SILU_GU16) {
         // panels alternate gate / up: odd waves hand their tile to the even wave on their left (LDS is free now)
         __syncthreads();
@@ -1435,7 +1473,7 @@ template <int MT, int EPI>
 static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
     const int blocks = cdiv((p.N + 15) >> 4, 8), chunks = p.K / 64;
     int ks = 1;
-    if (p.ws && blocks < 200) {                                      // few column groups: split K over workgroups
+    if (p.ws && blocks < 200 && !p.row_ssq) {                        // few column groups: split K over workgroups
         ks = cdiv(256, blocks);
         ks = ks > 8 ? 8 : ks;
         if (ks > chunks / 8) ks = chunks / 8;
@@ -1483,9 +1521,7 @@ static hipError_t launch_mid_t(const GemmParams &p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_mid_kernel<MT, EPI, NORM>), dim3(blocks, ks), dim3(256), lds, s, p, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
-    const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, p, ks);
-    return hipGetLastError();
+    return launch_reduce<EPI>(p, ks, s);
 }
 
 template <int EPI, bool NORM>
@@ -1563,9 +1599,13 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(ntile * ks), dim3(256), 65536, s, p, tm, tn, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
-    const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, p, ks);
-    return hipGetLastError();
+    return launch_reduce<EPI>(p, ks, s);
+}
+
+bool gemm_goes_wide(int M, int N) {
+    static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr, mid_v1 = getenv("OPUS_MID_V1") != nullptr;
+    if (mid_v1 || N < 16384 || M <= SKINNY_MAX_M || M > 96) return false;
+    return M > MID_MAX_M || !no_mid;
 }
 
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
