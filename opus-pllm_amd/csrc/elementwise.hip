@@ -309,31 +309,53 @@ hipError_t launch_lora_merge(half_t *W, const half_t *A, const half_t *B, float 
 // index, [4b+2] = #placeholders, [4b+3] = #valid ids.  plan[4B] = max length, plan[4B+1] = protein
 // blocks consumed (a row without placeholder consumes one: opus_arch.py:196-203), plan[4B+2] = 1 if
 // an id is outside [0,V) and != -200.
-__global__ void splice_plan_kernel(const int64_t *__restrict__ ids, const uint8_t *__restrict__ mask, int B, int Tt,
-                                   int n_tok, int max_len, int V, int32_t *__restrict__ plan) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int seq = 0, tmax = 0, bad = 0;
-    for (int b = 0; b < B; ++b) {
-        int nv = 0, nph = 0;
-        for (int t = 0; t < Tt; ++t) {
-            if (mask && !mask[(int64_t)b * Tt + t]) continue;
-            const int64_t id = ids[(int64_t)b * Tt + t];
-            ++nv;
-            if (id == -200) ++nph;
-            else if (id < 0 || id >= V) bad = 1;
+__global__ __launch_bounds__(1024) void splice_plan_kernel(const int64_t *__restrict__ ids, const uint8_t *__restrict__ mask, int B, int Tt,
+                                                         int n_tok, int max_len, int V, int32_t *__restrict__ plan) {
+    // 16 lanes per row count its valid ids / placeholders / out-of-range ids; the (short) scan over rows is serial
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, sub = tid & 15;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + (tid >> 4);
+        int nv = 0, nph = 0, bad = 0;
+        if (b < B) {
+            for (int t = sub; t < Tt; t += 16) {
+                if (mask && !mask[(int64_t)b * Tt + t]) continue;
+                const int64_t id = ids[(int64_t)b * Tt + t];
+                ++nv;
+                if (id == -200) ++nph;
+                else if (id < 0 || id >= V) bad = 1;
+            }
         }
-        int len = nv - nph + nph * n_tok;
-        if (max_len > 0 && len > max_len) len = max_len;
-        plan[4 * b + 0] = len;
-        plan[4 * b + 1] = seq;
-        plan[4 * b + 2] = nph;
-        plan[4 * b + 3] = nv;
-        seq += nph > 0 ? nph : 1;
-        tmax = len > tmax ? len : tmax;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            nv += __shfl_xor(nv, o, 64);
+            nph += __shfl_xor(nph, o, 64);
+            bad |= __shfl_xor(bad, o, 64);
+        }
+        if (b < B && sub == 0) {
+            int len = nv - nph + nph * n_tok;
+            if (max_len > 0 && len > max_len) len = max_len;
+            plan[4 * b + 0] = len;
+            plan[4 * b + 2] = nph;
+            plan[4 * b + 3] = nv;
+            if (bad) atomicOr(&s_bad, 1);
+        }
     }
-    plan[4 * B] = tmax;
-    plan[4 * B + 1] = seq;
-    plan[4 * B + 2] = bad;
+    __syncthreads();                      // plan[] rows written by this workgroup are visible to thread 0 (same CU, after the barrier)
+    if (tid == 0) {
+        int seq = 0, tmax = 0;
+        for (int b = 0; b < B; ++b) {
+            plan[4 * b + 1] = seq;
+            const int nph = plan[4 * b + 2], len = plan[4 * b];
+            seq += nph > 0 ? nph : 1;
+            tmax = len > tmax ? len : tmax;
+        }
+        plan[4 * B] = tmax;
+        plan[4 * B + 1] = seq;
+        plan[4 * B + 2] = s_bad;
+    }
 }
 __global__ __launch_bounds__(256) void splice_fill_kernel(const int64_t *__restrict__ ids, const uint8_t *__restrict__ mask,
                                                           int Tt, const half_t *__restrict__ prot, int n_tok, int H, int V,
@@ -376,7 +398,7 @@ __global__ __launch_bounds__(256) void splice_fill_kernel(const int64_t *__restr
 
 hipError_t launch_splice_plan(const int64_t *ids, const uint8_t *mask, int B, int Tt, int n_tok, int max_len, int V,
                                 int32_t *plan, hipStream_t s) {
-    hipLaunchKernelGGL(splice_plan_kernel, dim3(1), dim3(64), 0, s, ids, mask, B, Tt, n_tok, max_len, V, plan);
+    hipLaunchKernelGGL(splice_plan_kernel, dim3(1), dim3(1024), 0, s, ids, mask, B, Tt, n_tok, max_len, V, plan);
     return hipGetLastError();
 }
 hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, int Tt, const half_t *prot, int n_tok,
