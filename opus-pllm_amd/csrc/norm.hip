@@ -102,8 +102,15 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float *__restric
     if (d >= D) return;
     const int n = lens[b] - 2;
     const float *p = h + ((int64_t)b * T + 1) * D + d;
-    float s = 0.f;
-    for (int t = 0; t < n; ++t) s += p[(int64_t)t * D];
+    // eight interleaved partial sums (t mod 8) keep eight loads in flight; combined in a fixed order
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int t = 0;
+    for (; t + 8 <= n; t += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8[k] += p[(int64_t)(t + k) * D];
+    }
+    for (int k = 0; t < n; ++t, ++k) s8[k] += p[(int64_t)t * D];
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     out[(int64_t)b * D + d] = s / (float)n;   // n == 0 -> NaN, as torch's mean over an empty slice
 }
 
