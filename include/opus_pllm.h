@@ -175,7 +175,8 @@ int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const 
 
 /* Measurement support (bench.py): cumulative device time in ms of one kernel class since the last
  * reset, measured with hipEvents on the launch stream when timing is enabled (off by default).
- * class names: "skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other". */
+ * class names: "skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other", "decode_stack" (the opt-in persistent
+ * decode step). */
 int opus_timing_enable(opus_ctx *ctx, int32_t on);
 int opus_timing_reset(opus_ctx *ctx);
 int opus_timing_get(opus_ctx *ctx, const char *kernel_class, double *ms, int64_t *launches, double *bytes);
