@@ -12,9 +12,11 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
-// M up to which the weight-streaming skinny kernel is used (LDS-staged activations, fused RMSNorm);
-// above it the LDS-tiled MFMA kernel (with split-K when the output has few tiles) streams the weights.
-constexpr int SKINNY_MAX_M = 16;
+// M up to which the weight-streaming skinny kernel CAN be used (LDS-staged activations, fused RMSNorm); the mid / wide
+// kernels take over above skinny_max_m().
+constexpr int SKINNY_MAX_M_CAP = 16;
+int skinny_max_m();   // rows up to which the skinny kernel is used (default 4, at most 16; OPUS_SKINNY_MAX_M tunes it)
+#define SKINNY_MAX_M skinny_max_m()
 // M up to which the mid kernel (LDS-shared activations, per-wave weight stream, fused RMSNorm) is used
 constexpr int MID_MAX_M = 64;   // (65..128 rows measured faster on the split-K tile kernel)
 enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_STACK = 5, KC_COUNT = 6 };

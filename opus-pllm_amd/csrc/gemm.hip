@@ -1602,6 +1602,15 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     return launch_reduce<EPI>(p, ks, s);
 }
 
+int skinny_max_m() {
+    static const int v = [] {
+        const char *e = getenv("OPUS_SKINNY_MAX_M");
+        const int x = e ? atoi(e) : 4;      // measured: batch 8 149 vs 166 ms, batch 16 168 vs 210 ms with 5..16 rows on the mid / wide kernels
+        return x < 1 ? 1 : (x > SKINNY_MAX_M_CAP ? SKINNY_MAX_M_CAP : x);
+    }();
+    return v;
+}
+
 bool gemm_goes_wide(int M, int N) {
     static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr, mid_v1 = getenv("OPUS_MID_V1") != nullptr;
     if (mid_v1 || N < 16384 || M <= SKINNY_MAX_M || M > 96) return false;
