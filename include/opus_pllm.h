@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 2
+#define OPUS_ABI_VERSION 3
 
 enum opus_status {
     OPUS_OK = 0,
@@ -110,7 +110,9 @@ int opus_esm2_last_hidden(opus_ctx *ctx, float *d_out, int32_t B, int32_t T, voi
 /* Rows P1+P2: encode_projector_embedding + switch_projector_embedding (opus_arch.py:115-131,
  * modelling.py:396-400, protein_mlp/builder.py:11-25): pooled fp32 [B,enc_dim] ->
  * fp16 [B, n_prot_tokens, dec_dim].  d_proj_out (optional, may be NULL) receives the P1 output
- * fp16 [B, proj_dim]. */
+ * fp16 [B, proj_dim].  B is NOT limited by max_batch: the batched stage of the two-stage pipeline (SURVEY 8f N3,
+ * opus_arch.py:151-161 + scripts/generate_esm_embedding.py) projects whole dataset shards at M >= 512, in chunks of
+ * max(max_batch, 1024) rows.  has_protein_projector = 0 is the identity module of opus_arch.py:70-80: P1 is a cast. */
 int opus_projector_forward(opus_ctx *ctx, const float *d_pooled, int32_t B, void *d_out, void *d_proj_out,
                            void *stream);
 /* Row P1 alone: encode_projector_embedding (opus_arch.py:115-121): fp32 [B,enc_dim] -> fp16 [B,proj_dim]. */
@@ -169,17 +171,31 @@ int opus_debug_gemm(opus_ctx *ctx, const void *d_A, const void *d_W, const float
 /* Same with the fused RMSNorm prologue: A is fp32 [M,K], C = epi(rmsnorm(A) W^T) (norm weight folded in W). */
 int opus_debug_gemm_norm(opus_ctx *ctx, const float *d_A, const void *d_W, void *d_C, int32_t M, int32_t N, int32_t K,
                          int32_t epi, int32_t out_f32, float eps, void *stream);
+/* The row-scale RMSNorm fusion as the decoder issues it (api.cpp prefill / decode_step): X <- X + A W1^T through a
+ * split-K GEMM whose reduce also writes fp16(X) and per-256-column sums of squares, then C = epi(rmsnorm(X) W2^T) with
+ * the rows scaled inside the consumer GEMM.  A fp16 [M,K1], W1 [N1,K1] and W2 [N2,N1] panel-tiled, X fp32 [M,N1] in/out,
+ * C fp16 [M, N2 or N2/2]; *fused (HOST) = 1 when the fused kernels ran. */
+int opus_debug_gemm_rowscale(opus_ctx *ctx, const void *d_A, const void *d_W1, float *d_X, const void *d_W2, void *d_C,
+                             int32_t M, int32_t N1, int32_t K1, int32_t N2, int32_t epi, float eps, int32_t *fused,
+                             void *stream);
 int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const void *d_V, void *d_O,
                          const int32_t *d_kstart, const int32_t *d_kend, int32_t B, int32_t T, int32_t heads,
                          int32_t group, int32_t head_dim, int32_t causal, float scale, void *stream);
 
-/* Measurement support (bench.py): cumulative device time in ms of one kernel class since the last
- * reset, measured with hipEvents on the launch stream when timing is enabled (off by default).
- * class names: "skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other", "decode_stack" (the opt-in persistent
- * decode step). */
+/* fp32 logits [B, dec_vocab] of the most recent prefill / decode step (device copy on `stream`): the payload of the
+ * optional logits all-gather of SURVEY 8e (ids are what eval/run_opus_ddp.py:138 gathers). */
+int opus_last_logits(opus_ctx *ctx, float *d_out, int32_t B, void *stream);
+
+/* Measurement support (bench.py).  With timing enabled (off by default; decode runs eagerly instead of from the
+ * hipGraph) every kernel launch of the path is recorded with its own dispatch start / end events on the launch stream
+ * (hipExtLaunchKernelGGL - the interval rocprofv3 --kernel-trace reports), its kernel class, the phase of the path it
+ * belongs to, and its ALGORITHMIC bytes and FLOPs.  opus_timing_get sums the records since the last reset that match
+ * kernel_class and phase ("*" = any); opus_timing_names returns "class,class,...;phase,phase,..." . */
 int opus_timing_enable(opus_ctx *ctx, int32_t on);
 int opus_timing_reset(opus_ctx *ctx);
-int opus_timing_get(opus_ctx *ctx, const char *kernel_class, double *ms, int64_t *launches, double *bytes);
+int opus_timing_get(opus_ctx *ctx, const char *kernel_class, const char *phase, double *ms, int64_t *launches, double *bytes,
+                    double *flops);
+int opus_timing_names(char *buf, int32_t cap);
 
 #ifdef __cplusplus
 }

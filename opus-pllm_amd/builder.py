@@ -101,7 +101,8 @@ def _load_torch_bin_dir(path: str) -> Dict[str, torch.Tensor]:
     return sd
 
 
-def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, switch_depth: int = 2, **cap) -> OpusConfig:
+def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, switch_depth: int = 2,
+                   has_protein_projector: int = 1, **cap) -> OpusConfig:
     """HF config.json (Llama, Qwen2 or OPT / Galactica) + the reference's hard-coded protein dims -> OpusConfig."""
     H, nh = hf_cfg["hidden_size"], hf_cfg["num_attention_heads"]
     if hf_cfg.get("model_type") == "opt":
@@ -111,7 +112,7 @@ def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, sw
             raise NotImplementedError("OPT with project_in / project_out (word_embed_proj_dim != hidden_size) is not built")
         if hf_cfg.get("activation_function", "relu") != "gelu":
             raise NotImplementedError("only the GELU OPT variants (Galactica) are built")
-        return OpusConfig(**esm2_dims(esm), proj_dim=proj_dim, switch_depth=switch_depth, dec_arch=1,
+        return OpusConfig(**esm2_dims(esm), proj_dim=proj_dim, switch_depth=switch_depth, has_protein_projector=has_protein_projector, dec_arch=1,
                           dec_layers=hf_cfg["num_hidden_layers"], dec_dim=H, dec_heads=nh, dec_kv_heads=nh,
                           dec_head_dim=H // nh, dec_ffn=hf_cfg["ffn_dim"], dec_vocab=hf_cfg["vocab_size"], dec_rms_eps=1e-5,
                           dec_max_pos=hf_cfg.get("max_position_embeddings", 2048), **cap).validate()
@@ -123,7 +124,7 @@ def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, sw
     rope = hf_cfg.get("rope_theta") or (hf_cfg.get("rope_parameters") or {}).get("rope_theta", 10000.0)
     if hf_cfg.get("rope_scaling"):
         raise NotImplementedError("rope_scaling is not built (Llama-3-8B and Vicuna use plain rotary)")
-    return OpusConfig(**esm2_dims(esm), proj_dim=proj_dim, switch_depth=switch_depth,
+    return OpusConfig(**esm2_dims(esm), proj_dim=proj_dim, switch_depth=switch_depth, has_protein_projector=has_protein_projector,
                       dec_layers=hf_cfg["num_hidden_layers"], dec_dim=H, dec_heads=nh,
                       dec_kv_heads=hf_cfg.get("num_key_value_heads", nh), dec_head_dim=hf_cfg.get("head_dim") or H // nh,
                       dec_ffn=hf_cfg["intermediate_size"], dec_vocab=hf_cfg["vocab_size"],
@@ -210,6 +211,14 @@ def lora_from_peft(adapter_dir: str, cfg: OpusConfig) -> Dict[str, Tuple[torch.T
     with open(os.path.join(adapter_dir, "adapter_config.json")) as f:
         ac = json.load(f)
     r, alpha = int(ac["r"]), float(ac["lora_alpha"])
+    # options that change what merge_and_unload computes and that the load-time merge (W += (alpha / r) B A) does not cover
+    for opt in ("use_rslora", "use_dora", "fan_in_fan_out"):
+        if ac.get(opt):
+            raise NotImplementedError(f"PEFT option {opt}=true is not supported by the load-time LoRA merge")
+    if ac.get("rank_pattern") or ac.get("alpha_pattern"):
+        raise NotImplementedError("PEFT rank_pattern / alpha_pattern are not supported by the load-time LoRA merge")
+    if ac.get("modules_to_save"):
+        raise NotImplementedError(f"PEFT modules_to_save={ac['modules_to_save']} is not supported")
     st = os.path.join(adapter_dir, "adapter_model.safetensors")
     if os.path.exists(st):
         from safetensors.torch import load_file
@@ -223,10 +232,10 @@ def lora_from_peft(adapter_dir: str, cfg: OpusConfig) -> Dict[str, Tuple[torch.T
         if "lora_A" not in k:
             continue
         parts = k.split(".")
-        l = int(parts[parts.index("layers") + 1])
         mod = next((names[p] for p in parts if p in names), None)
-        if mod is None:
-            raise NotImplementedError(f"LoRA target outside the decoder projections: {k}")
+        if mod is None or "layers" not in parts:
+            raise NotImplementedError(f"LoRA target outside the decoder layers' projections (lm_head / embeddings?): {k}")
+        l = int(parts[parts.index("layers") + 1])
         out[f"dec.layers.{l}.{mod}.weight"] = (A, sd[k.replace("lora_A", "lora_B")], alpha, r)
     return out
 
@@ -257,8 +266,11 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
     if not (model_name is not None and model_base_path):
         raise NotImplementedError
 
+    # model_args.pretrain_protein_projector_ckpt = cstp_path (builder.py:40): None selects the identity protein projector and a
+    # switch projector fed by the raw encoder width (opus_arch.py:70-80, protein_mlp/builder.py:14)
+    has_proj = 0 if cstp_path is None else 1
     if str(model_base_path).startswith("synthetic:"):
-        cfg = PRESETS[model_base_path.split(":", 1)[1]](switch_depth=depth, **cap)
+        cfg = PRESETS[model_base_path.split(":", 1)[1]](switch_depth=depth, has_protein_projector=has_proj, **cap)
         weights = DeviceWeights.synthetic(cfg, int(kwargs.pop("seed", 0)), device)
         tokenizer = SyntheticTokenizer(cfg.dec_vocab)
         model = OpusLlamaForCausalLM(cfg, weights, device, eos_token_id=tokenizer.eos_token_id,
@@ -277,7 +289,7 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
         raise NotImplementedError
     with open(os.path.join(model_base_path, "config.json")) as f:
         hf_cfg = json.load(f)
-    cfg = config_from_hf(hf_cfg, switch_depth=depth, **cap)
+    cfg = config_from_hf(hf_cfg, switch_depth=depth, has_protein_projector=has_proj, **cap)
     if (family == "opt") != (cfg.dec_arch == 1):
         raise ValueError(f"{model_base_path}: path says '{family}' but config.json model_type is {hf_cfg.get('model_type')!r}")
     import transformers
@@ -302,12 +314,19 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
         print("No adapter path!")
     if isinstance(cstp_path, str):
         canon.update(canonical_from_cstp(torch.load(cstp_path, map_location="cpu", weights_only=False)))
-    else:
-        raise NotImplementedError("the identity protein projector (no CSTP checkpoint, opus_arch.py:70-80) is not built")
+    elif cstp_path is not None:
+        raise ValueError("cstp_path must be the path of modality_encoding_adapter.ckpt, or None for the identity protein "
+                         "projector (the reference's default `True` is a placeholder its own loader cannot open)")
     esm = torch.load(_esm2_ckpt_path(), map_location="cpu", weights_only=False)
     canon.update(canonical_from_esm2(esm.get("model", esm), cfg))
     weights = DeviceWeights.from_canonical(cfg, canon, device, lora=lora)
+    # HF generate() stops on model.generation_config, which from_pretrained reads from generation_config.json when the
+    # file exists (Llama-3-Instruct lists [128001, 128009] there and a single id in config.json)
     eos = hf_cfg.get("eos_token_id", tokenizer.eos_token_id)
+    gc_path = os.path.join(model_base_path, "generation_config.json")
+    if os.path.exists(gc_path):
+        with open(gc_path) as f:
+            eos = json.load(f).get("eos_token_id", eos)
     model = OpusLlamaForCausalLM(cfg, weights, device, eos_token_id=eos, pad_token_id=tokenizer.pad_token_id)
     context_len = hf_cfg.get("max_sequence_length", 512)     # builder.py:126-129
     return tokenizer, model, context_len

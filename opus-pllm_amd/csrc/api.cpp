@@ -55,9 +55,9 @@ struct DecLayer {   // arch 0: RMSNorm weights are folded into wqkv / wgu (and d
 };
 
 struct TimeRec {
-    int klass;
+    int klass, phase;
     hipEvent_t e0, e1;
-    double bytes;
+    double bytes, flops;
 };
 
 struct opus_ctx {
@@ -111,7 +111,10 @@ struct opus_ctx {
     float row_eps = 0.f;
     // timing
     bool timing = false;
+    int phase = PH_OTHER;
     std::vector<TimeRec> recs;
+    // rows the projector workspace (p_xn, p_y, p_z) holds: larger batches are projected in chunks of this many rows
+    int proj_rows = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -140,10 +143,13 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->e_ctx = k.take<half_t>(Me * De);
     c->e_h1 = k.take<half_t>(Me * Fe);
     const size_t B = g.max_batch, H = g.dec_dim, SW = (size_t)g.dec_dim * g.n_prot_tokens;
-    c->p_xn = k.take<half_t>(B * De);
-    c->p_y = k.take<half_t>(B * (size_t)(g.has_protein_projector ? g.proj_dim : g.enc_dim));
-    c->p_z[0] = k.take<half_t>(B * SW);
-    c->p_z[1] = k.take<half_t>(B * SW);
+    // the projectors also serve the batched stage of the two-stage pipeline (whole shards at M >= 512)
+    const size_t PR = B > 1024 ? B : 1024;
+    c->proj_rows = (int)PR;
+    c->p_xn = k.take<half_t>(PR * De);
+    c->p_y = k.take<half_t>(PR * (size_t)(g.has_protein_projector ? g.proj_dim : g.enc_dim));
+    c->p_z[0] = k.take<half_t>(PR * SW);
+    c->p_z[1] = k.take<half_t>(PR * SW);
     const size_t Md = B * g.max_prompt;
     const size_t QKV = (size_t)(g.dec_heads + 2 * g.dec_kv_heads) * g.dec_head_dim;
     const size_t QD = (size_t)g.dec_heads * g.dec_head_dim;
@@ -302,6 +308,9 @@ extern "C" int opus_bind_weight(opus_ctx *c, const char *name, const void *d_ptr
     t.shape.assign(shape, shape + ndim);
     c->w[name] = t;
     c->resolved = false;
+    // a captured decode graph holds the device pointers of the weights it was recorded with
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    c->g_B = -1;
     return OPUS_OK;
 }
 
@@ -406,24 +415,38 @@ extern "C" int opus_weights_ready(opus_ctx *c) {
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
+// Per-launch timing (timing mode only): the principal kernel of the bracketed call is dispatched with its own start /
+// end events (OPUS_LAUNCH), a split-K reduce behind it with a second pair; a call that launches through plain
+// hipLaunchKernelGGL falls back to events recorded around it on the stream.
 struct Timed {
     opus_ctx *c;
     hipStream_t s;
     int klass;
-    double bytes;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    Timed(opus_ctx *c_, hipStream_t s_, int k, double b) : c(c_), s(s_), klass(k), bytes(b) {
+    double bytes, flops;
+    LaunchEvents ev;
+    hipEvent_t b0 = nullptr, b1 = nullptr;
+    Timed(opus_ctx *c_, hipStream_t s_, int k, double b, double f = 0.0) : c(c_), s(s_), klass(k), bytes(b), flops(f) {
         if (c->timing) {
-            (void)hipEventCreate(&e0);
-            (void)hipEventCreate(&e1);
-            (void)hipEventRecord(e0, s);
+            (void)hipEventCreate(&ev.main0); (void)hipEventCreate(&ev.main1);
+            (void)hipEventCreate(&ev.aux0); (void)hipEventCreate(&ev.aux1);
+            (void)hipEventCreate(&b0); (void)hipEventCreate(&b1);
+            (void)hipEventRecord(b0, s);
+            tl_launch_ev = &ev;
         }
     }
     ~Timed() {
-        if (c->timing) {
-            (void)hipEventRecord(e1, s);
-            c->recs.push_back(TimeRec{klass, e0, e1, bytes});
+        if (!c->timing) return;
+        tl_launch_ev = nullptr;
+        if (ev.main_used) {
+            c->recs.push_back(TimeRec{ev.main_class >= 0 ? ev.main_class : klass, c->phase, ev.main0, ev.main1, bytes, flops});
+            (void)hipEventDestroy(b0); (void)hipEventDestroy(b1);
+        } else {
+            (void)hipEventRecord(b1, s);
+            c->recs.push_back(TimeRec{klass, c->phase, b0, b1, bytes, flops});
+            (void)hipEventDestroy(ev.main0); (void)hipEventDestroy(ev.main1);
         }
+        if (ev.aux_used) c->recs.push_back(TimeRec{KC_REDUCE, c->phase, ev.aux0, ev.aux1, ev.aux_bytes, 0.0});
+        else { (void)hipEventDestroy(ev.aux0); (void)hipEventDestroy(ev.aux1); }
     }
 };
 
@@ -434,25 +457,19 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     p.A = A; p.Af = Af; p.norm_eps = eps; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.residual = residual; p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
     p.ws = c->gemm_ws; p.ws_bytes = c->gemm_ws_bytes;
-    p.ev0 = p.ev1 = nullptr;
     p.xh_out = c->rq_xh; p.ssq_out = c->d_ssq; p.fused_done = &c->rq_done;
     c->rq_done = 0;
     c->rq_xh = nullptr;                  // one-shot
     p.row_ssq = nullptr; p.row_nblk = 0;
     if (c->use_row_scale) { p.row_ssq = c->d_ssq; p.row_nblk = K >> 8; p.norm_eps = c->row_eps; c->use_row_scale = false; }
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
+    // algorithmic bytes: the weights once + activations in + result out (+ the residual read)
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
                          (residual ? 4.0 * M * nout : 0.0);
     int klass = M <= SKINNY_MAX_M ? KC_SKINNY : KC_TILE;
     hipError_t e;
-    if (c->timing && klass == KC_SKINNY) {
-        // the dominant kernel is timed by its own dispatch timestamps (hipExtLaunchKernelGGL start/stop events)
-        (void)hipEventCreate(&p.ev0);
-        (void)hipEventCreate(&p.ev1);
-        e = launch_gemm(p, s, &klass);
-        c->recs.push_back(TimeRec{klass, p.ev0, p.ev1, bytes});
-    } else {
-        Timed t(c, s, klass, bytes);
+    {
+        Timed t(c, s, klass, bytes, 2.0 * M * N * (double)K);
         e = launch_gemm(p, s, &klass);
     }
     if (e != hipSuccess) return fail(OPUS_EHIP, "gemm M=%d N=%d K=%d failed: %s", M, N, K, hipGetErrorString(e));
@@ -466,12 +483,16 @@ static bool fuse_rows() {
     static const bool off = getenv("OPUS_NO_ROW_FUSION") != nullptr;   // A/B aid
     return !off;
 }
-#define KL(klass, bytes, call)                                                                        \
+#define KLF(klass, bytes, flops, call)                                                                \
     do {                                                                                              \
-        Timed t_(c, s, klass, bytes);                                                                 \
-        hipError_t e_ = (call);                                                                       \
+        hipError_t e_;                                                                                \
+        {                                                                                             \
+            Timed t_(c, s, klass, bytes, flops);                                                      \
+            e_ = (call);                                                                              \
+        }                                                                                             \
         if (e_ != hipSuccess) return fail(OPUS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+#define KL(klass, bytes, call) KLF(klass, bytes, 0.0, call)
 
 // C = epi(rmsnorm(X) W'^T) with the norm weight pre-folded into W': fused in the skinny kernel (M <= 64),
 // otherwise a weight-less rmsnorm kernel into `scratch` followed by the tile kernel.
@@ -492,7 +513,7 @@ static int gemm_norm(opus_ctx *c, hipStream_t s, const float *X, float eps, half
     const bool wide = M > SKINNY_MAX_M && N >= 16384 && !mid_v1;
     if (M <= SKINNY_MAX_M || (M <= MID_MAX_M && !no_mid && !wide))
         return gemm_any(c, s, nullptr, X, eps, K, W, M, N, K, bias, epi, nullptr, C, ldc, out_f32);
-    KL(KC_OTHER, 6.0 * M * K, launch_rmsnorm(X, nullptr, eps, M, K, scratch, s));
+    KL(KC_NORM, 6.0 * M * K, launch_rmsnorm(X, nullptr, eps, M, K, scratch, s));
     return gemm(c, s, scratch, K, W, M, N, K, bias, epi, nullptr, C, ldc, out_f32);
 }
 
@@ -540,12 +561,13 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
     if (B < 1 || B > g.max_batch || T < 3 || T > g.max_enc_tokens)
         return fail(OPUS_ESHAPE, "esm2_encode: B=%d T=%d exceed capacity (%d, %d)", B, T, g.max_batch, g.max_enc_tokens);
     hipStream_t s = (hipStream_t)stream;
+    c->phase = PH_ENCODE;
     const int D = g.enc_dim, F = g.enc_ffn, nh = g.enc_heads, hd = D / nh;
     const int M = B * T;
     KL(KC_OTHER, 4.0 * M * D, launch_esm_embed(d_tokens, c->enc_emb, B, T, D, c->e_x, s));
     for (int l = 0; l < g.enc_layers; ++l) {
         const EncLayer &L = c->enc[l];
-        KL(KC_OTHER, 6.0 * M * D, launch_layernorm(c->e_x, L.ln1w, L.ln1b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
+        KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, L.ln1w, L.ln1b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
         OPC(gemm(c, s, c->e_xn, D, L.wqkv, M, 3 * D, D, L.bqkv, EPI_NONE, nullptr, c->e_qkv, 3 * D, 0));
         KL(KC_OTHER, 8.0 * M * D, launch_esm_rope(c->e_qkv, c->cs_enc, B, T, nh, hd, 1.0f / sqrtf((float)hd), s));
         AttnParams a;
@@ -555,13 +577,13 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
         a.O = c->e_ctx; a.o_sb = (int64_t)T * D; a.o_st = D;
         a.kstart = nullptr; a.kend = d_lens;
         a.B = B; a.T = T; a.heads = nh; a.group = 1; a.head_dim = hd; a.causal = 0; a.scale = 1.0f;
-        KL(KC_ATTN_PREFILL, 8.0 * M * D, launch_attn_prefill(a, s));
+        KLF(KC_ATTN_PREFILL, 8.0 * M * D, 4.0 * B * (double)T * T * D, launch_attn_prefill(a, s));
         OPC(gemm(c, s, c->e_ctx, D, L.wo, M, D, D, L.bo, EPI_NONE, c->e_x, c->e_x, D, 1));
-        KL(KC_OTHER, 6.0 * M * D, launch_layernorm(c->e_x, L.ln2w, L.ln2b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
+        KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, L.ln2w, L.ln2b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
         OPC(gemm(c, s, c->e_xn, D, L.w1, M, F, D, L.b1, EPI_GELU, nullptr, c->e_h1, F, 0));
         OPC(gemm(c, s, c->e_h1, F, L.w2, M, D, F, L.b2, EPI_NONE, c->e_x, c->e_x, D, 1));
     }
-    KL(KC_OTHER, 8.0 * M * D, launch_layernorm(c->e_x, c->enc_lnfw, c->enc_lnfb, g.enc_ln_eps, M, D, nullptr, c->e_hid, s));
+    KL(KC_NORM, 8.0 * M * D, launch_layernorm(c->e_x, c->enc_lnfw, c->enc_lnfb, g.enc_ln_eps, M, D, nullptr, c->e_hid, s));
     KL(KC_OTHER, 4.0 * M * D, launch_masked_mean(c->e_hid, d_lens, B, T, D, d_pooled, s));
     return OPUS_OK;
 }
@@ -575,31 +597,28 @@ extern "C" int opus_esm2_last_hidden(opus_ctx *c, float *d_out, int32_t B, int32
 }
 
 // ------------------------------------------------------------------------------------------------ projectors
-extern "C" int opus_protein_projector(opus_ctx *c, const float *d_pooled, int32_t B, void *d_out, void *stream) {
-    OPC(need_ready(c));
-    if (!d_pooled || !d_out) return fail(OPUS_EBADARG, "protein_projector: null pointer");
+// The projector workspace holds c->proj_rows rows; larger inputs (the batched stage of the two-stage pipeline, SURVEY 8f N3:
+// whole dataset shards at M >= 512, where the switch-projector GEMMs are MFMA-bound) are processed in chunks of that size.
+static int protein_projector_rows(opus_ctx *c, hipStream_t s, const float *d_pooled, int B, half_t *d_out) {
     const opus_config &g = c->cfg;
-    if (B < 1 || B > g.max_batch) return fail(OPUS_ESHAPE, "protein_projector: B=%d exceeds max_batch=%d", B, g.max_batch);
-    if (!g.has_protein_projector)
-        return fail(OPUS_EUNSUPPORTED, "has_protein_projector = 0 (identity projector, opus_arch.py:70-80) is not built");
-    hipStream_t s = (hipStream_t)stream;
     const int De = g.enc_dim;
-    KL(KC_OTHER, 6.0 * B * De, launch_l2norm(d_pooled, B, De, c->p_xn, s));
+    if (!g.has_protein_projector) {
+        // IdentityModule.protein_forward (opus_arch.py:70-80): the pooled embedding itself feeds the switch projector,
+        // whose autocast Linear rounds it to fp16
+        KL(KC_OTHER, 6.0 * B * De, launch_f2h(d_pooled, (int64_t)B * De, d_out, s));
+        return OPUS_OK;
+    }
+    KL(KC_NORM, 6.0 * B * De, launch_l2norm(d_pooled, B, De, c->p_xn, s));
     return gemm(c, s, c->p_xn, De, c->proj_w, B, g.proj_dim, De, c->proj_b, EPI_NONE, nullptr, d_out, g.proj_dim, 0);
 }
 
-extern "C" int opus_switch_projector(opus_ctx *c, const void *d_in, int32_t B, void *d_out, void *stream) {
-    OPC(need_ready(c));
-    if (!d_in || !d_out) return fail(OPUS_EBADARG, "switch_projector: null pointer");
+static int switch_projector_rows(opus_ctx *c, hipStream_t s, const half_t *in, int B, half_t *d_out) {
     const opus_config &g = c->cfg;
-    if (B < 1 || B > g.max_batch) return fail(OPUS_ESHAPE, "switch_projector: B=%d exceeds max_batch=%d", B, g.max_batch);
-    hipStream_t s = (hipStream_t)stream;
     const int SW = g.dec_dim * g.n_prot_tokens;
     int din = g.has_protein_projector ? g.proj_dim : g.enc_dim;
-    const half_t *in = (const half_t *)d_in;
     for (int i = 0; i < g.switch_depth; ++i) {
         const bool last = i + 1 == g.switch_depth;
-        half_t *o = last ? (half_t *)d_out : c->p_z[i & 1];
+        half_t *o = last ? d_out : c->p_z[i & 1];
         // nn.GELU() sits between the Linear layers (protein_mlp/builder.py:21-24): fused as the epilogue
         OPC(gemm(c, s, in, din, c->sw_w[i], B, SW, din, c->sw_b[i], last ? EPI_NONE : EPI_GELU, nullptr, o, SW, 0));
         in = o;
@@ -608,14 +627,51 @@ extern "C" int opus_switch_projector(opus_ctx *c, const void *d_in, int32_t B, v
     return OPUS_OK;
 }
 
+extern "C" int opus_protein_projector(opus_ctx *c, const float *d_pooled, int32_t B, void *d_out, void *stream) {
+    OPC(need_ready(c));
+    if (!d_pooled || !d_out) return fail(OPUS_EBADARG, "protein_projector: null pointer");
+    if (B < 1) return fail(OPUS_ESHAPE, "protein_projector: B=%d", B);
+    const opus_config &g = c->cfg;
+    const int64_t din = g.enc_dim, dout = g.has_protein_projector ? g.proj_dim : g.enc_dim;
+    c->phase = PH_PROJECT;
+    for (int r0 = 0; r0 < B; r0 += c->proj_rows) {
+        const int n = B - r0 < c->proj_rows ? B - r0 : c->proj_rows;
+        OPC(protein_projector_rows(c, (hipStream_t)stream, d_pooled + r0 * din, n, (half_t *)d_out + r0 * dout));
+    }
+    return OPUS_OK;
+}
+
+extern "C" int opus_switch_projector(opus_ctx *c, const void *d_in, int32_t B, void *d_out, void *stream) {
+    OPC(need_ready(c));
+    if (!d_in || !d_out) return fail(OPUS_EBADARG, "switch_projector: null pointer");
+    if (B < 1) return fail(OPUS_ESHAPE, "switch_projector: B=%d", B);
+    const opus_config &g = c->cfg;
+    const int64_t din = g.has_protein_projector ? g.proj_dim : g.enc_dim, SW = (int64_t)g.dec_dim * g.n_prot_tokens;
+    c->phase = PH_PROJECT;
+    for (int r0 = 0; r0 < B; r0 += c->proj_rows) {
+        const int n = B - r0 < c->proj_rows ? B - r0 : c->proj_rows;
+        OPC(switch_projector_rows(c, (hipStream_t)stream, (const half_t *)d_in + r0 * din, n, (half_t *)d_out + r0 * SW));
+    }
+    return OPUS_OK;
+}
+
 extern "C" int opus_projector_forward(opus_ctx *c, const float *d_pooled, int32_t B, void *d_out, void *d_proj_out,
                                       void *stream) {
-    if (!c) return fail(OPUS_EBADARG, "ctx is null");
-    OPC(opus_protein_projector(c, d_pooled, B, c->p_y, stream));
-    if (d_proj_out)
-        HIPC(hipMemcpyAsync(d_proj_out, c->p_y, (size_t)B * c->cfg.proj_dim * sizeof(half_t), hipMemcpyDeviceToDevice,
-                            (hipStream_t)stream));
-    return opus_switch_projector(c, c->p_y, B, d_out, stream);
+    OPC(need_ready(c));
+    if (!d_pooled || !d_out) return fail(OPUS_EBADARG, "projector_forward: null pointer");
+    if (B < 1) return fail(OPUS_ESHAPE, "projector_forward: B=%d", B);
+    const opus_config &g = c->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t din = g.enc_dim, dmid = g.has_protein_projector ? g.proj_dim : g.enc_dim, SW = (int64_t)g.dec_dim * g.n_prot_tokens;
+    c->phase = PH_PROJECT;
+    for (int r0 = 0; r0 < B; r0 += c->proj_rows) {
+        const int n = B - r0 < c->proj_rows ? B - r0 : c->proj_rows;
+        OPC(protein_projector_rows(c, s, d_pooled + r0 * din, n, c->p_y));
+        if (d_proj_out)
+            HIPC(hipMemcpyAsync((half_t *)d_proj_out + r0 * dmid, c->p_y, (size_t)n * dmid * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+        OPC(switch_projector_rows(c, s, c->p_y, n, (half_t *)d_out + r0 * SW));
+    }
+    return OPUS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ splice
@@ -627,6 +683,7 @@ extern "C" int opus_splice_pad(opus_ctx *c, const int64_t *d_ids, const uint8_t 
     const opus_config &g = c->cfg;
     if (B < 1 || B > g.max_batch || Tt < 1) return fail(OPUS_ESHAPE, "splice_pad: B=%d T_text=%d out of range", B, Tt);
     hipStream_t s = (hipStream_t)stream;
+    c->phase = PH_SPLICE;
     KL(KC_OTHER, 9.0 * B * Tt, launch_splice_plan(d_ids, d_mask, B, Tt, g.n_prot_tokens, max_length, g.dec_vocab, c->d_plan, s));
     int32_t tail[3];
     HIPC(hipMemcpyAsync(tail, c->d_plan + 4 * B, sizeof(tail), hipMemcpyDeviceToHost, s));
@@ -659,7 +716,7 @@ static int opt_layer(opus_ctx *c, hipStream_t s, const DecLayer &L, int l, float
     const opus_config &g = c->cfg;
     const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
     const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
-    KL(KC_OTHER, 6.0 * M * H, launch_layernorm(x, L.ln1w, L.ln1b, g.dec_rms_eps, M, H, xn, nullptr, s));
+    KL(KC_NORM, 6.0 * M * H, launch_layernorm(x, L.ln1w, L.ln1b, g.dec_rms_eps, M, H, xn, nullptr, s));
     OPC(gemm(c, s, xn, H, L.wqkv, M, QKV, H, L.bqkv, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
     if (decode) {
         KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (T + 1),
@@ -678,10 +735,10 @@ static int opt_layer(opus_ctx *c, hipStream_t s, const DecLayer &L, int l, float
         a.kstart = c->d_kstart; a.kend = nullptr;
         a.B = B; a.T = T; a.heads = nh; a.group = nh / nkv; a.head_dim = hd; a.causal = 1;
         a.scale = 1.0f / sqrtf((float)hd);
-        KL(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), launch_attn_prefill(a, s));
+        KLF(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), 2.0 * B * (double)T * T * QD, launch_attn_prefill(a, s));
     }
     OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, L.bo, EPI_NONE, x, x, H, 1));
-    KL(KC_OTHER, 6.0 * M * H, launch_layernorm(x, L.ln2w, L.ln2b, g.dec_rms_eps, M, H, xn, nullptr, s));
+    KL(KC_NORM, 6.0 * M * H, launch_layernorm(x, L.ln2w, L.ln2b, g.dec_rms_eps, M, H, xn, nullptr, s));
     OPC(gemm(c, s, xn, H, L.w1, M, F, H, L.b1, EPI_GELU, nullptr, c->d_act, F, 0));
     OPC(gemm(c, s, c->d_act, F, L.w2, M, H, F, L.b2, EPI_NONE, x, x, H, 1));
     return OPUS_OK;
@@ -689,7 +746,7 @@ static int opt_layer(opus_ctx *c, hipStream_t s, const DecLayer &L, int l, float
 
 static int lm_head_opt(opus_ctx *c, hipStream_t s, int B) {
     const opus_config &g = c->cfg;
-    KL(KC_OTHER, 6.0 * B * g.dec_dim, launch_layernorm(c->d_xl, c->dec_lnfw, c->dec_lnfb, g.dec_rms_eps, B, g.dec_dim, c->d_xln, nullptr, s));
+    KL(KC_NORM, 6.0 * B * g.dec_dim, launch_layernorm(c->d_xl, c->dec_lnfw, c->dec_lnfb, g.dec_rms_eps, B, g.dec_dim, c->d_xln, nullptr, s));
     return gemm(c, s, c->d_xln, g.dec_dim, c->lm_head, B, g.dec_vocab, g.dec_dim, nullptr, EPI_NONE, nullptr, c->d_logits,
                 g.dec_vocab, 1);
 }
@@ -722,6 +779,7 @@ static int decode_step_opt(opus_ctx *c, hipStream_t s) {
 }
 
 static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8_t *mask, int B, int T) {
+    c->phase = PH_PREFILL;
     if (c->cfg.dec_arch == 1) return prefill_opt(c, s, embeds, mask, B, T);
     const opus_config &g = c->cfg;
     const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
@@ -743,7 +801,7 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
         a.kstart = c->d_kstart; a.kend = nullptr;
         a.B = B; a.T = T; a.heads = nh; a.group = nh / nkv; a.head_dim = hd; a.causal = 1;
         a.scale = 1.0f / sqrtf((float)hd);
-        KL(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), launch_attn_prefill(a, s));
+        KLF(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), 2.0 * B * (double)T * T * QD, launch_attn_prefill(a, s));
         if (fuse_rows() && M <= 96) c->rq_xh = c->d_xn;      // (d_ssq holds 128 rows)
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
         c->xh_src = c->rq_done ? c->d_x : nullptr;
@@ -780,6 +838,7 @@ static int stack_check(opus_ctx *c) {
 // One decode step for the token ids in d_tok (device): embeds them, runs the stack at slot T + *step,
 // leaves logits in c->d_logits and advances *step.
 static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
+    c->phase = PH_DECODE;
     const opus_config &g = c->cfg;
     const int B = c->cur_B, T = c->cur_T;
     const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
@@ -807,14 +866,7 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
         // algorithmic bytes of the launch: every decoder weight once + the rows' K/V history
         const double wbytes = 2.0 * ((double)g.dec_layers * ((double)QKV * H + (double)H * QD + 3.0 * F * H) + (double)g.dec_vocab * H);
         const double bytes = wbytes + 4.0 * g.dec_layers * B * nkv * hd * (T + 1);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->timing) {
-            (void)hipEventCreate(&e0);
-            (void)hipEventCreate(&e1);
-        }
-        hipError_t e = launch_decode_stack(sp, hd, s, e0, e1);
-        if (c->timing) c->recs.push_back(TimeRec{KC_STACK, e0, e1, bytes});
-        if (e != hipSuccess) return fail(OPUS_EHIP, "decode stack launch failed: %s", hipGetErrorString(e));
+        KLF(KC_STACK, bytes, 0.5 * wbytes * 2.0 * B, launch_decode_stack(sp, hd, s));
         KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
         return OPUS_OK;
     }
@@ -872,6 +924,7 @@ extern "C" int opus_llama_decode_step(opus_ctx *c, const int32_t *d_tok, float *
 
 // next token per row: argmax (greedy) or temperature / top-p sampling, then the GenerationMixin bookkeeping
 static int argmax(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id, int32_t *d_out) {
+    c->phase = PH_DECODE;
     const opus_config &g = c->cfg;
     const int32_t *chosen = nullptr;
     if (c->samp_temp > 0.f) {
@@ -1030,6 +1083,38 @@ extern "C" int opus_debug_gemm_norm(opus_ctx *c, const float *A, const void *W, 
                     out_f32);
 }
 
+// The producer / consumer pair of the row-scale RMSNorm fusion exactly as prefill() and decode_step() issue it:
+//   X <- X + A W1^T            (wo: a split-K GEMM whose reduce also writes fp16(X) and per-256-column sums of squares)
+//   C  = epi(rmsnorm(X) W2^T)  (gate/up or lm_head: gemm_wide_kernel scales its rows by the rstd from those sums)
+// *fused = 1 when the fused form ran (0: the separate-norm fallback ran; the result is the same function either way).
+extern "C" int opus_debug_gemm_rowscale(opus_ctx *c, const void *A, const void *W1, float *X, const void *W2, void *Cp, int32_t M,
+                                        int32_t N1, int32_t K1, int32_t N2, int32_t epi, float eps, int32_t *fused, void *stream) {
+    if (!c || !A || !W1 || !X || !W2 || !Cp || !fused) return fail(OPUS_EBADARG, "debug_gemm_rowscale: null pointer");
+    if (M < 1 || N1 < 64 || N1 % 64 || K1 < 64 || K1 % 64 || N2 < 32) return fail(OPUS_ESHAPE, "debug_gemm_rowscale: shape");
+    if (epi != EPI_NONE && epi != EPI_SILU_GU16) return fail(OPUS_EBADARG, "debug_gemm_rowscale: epilogue 0 or 2");
+    const opus_config &g = c->cfg;
+    if ((int64_t)M * N1 > (int64_t)g.max_batch * g.max_prompt * g.dec_dim) return fail(OPUS_ESHAPE, "debug_gemm_rowscale: M * N1 exceeds the scratch");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (fuse_rows() && M <= 96) c->rq_xh = c->d_xn;
+    OPC(gemm(c, s, (const half_t *)A, K1, (const half_t *)W1, M, N1, K1, nullptr, EPI_NONE, X, X, N1, 1));
+    c->xh_src = c->rq_done ? X : nullptr;
+    *fused = c->xh_src != nullptr && (N1 & 255) == 0 && gemm_goes_wide(M, N2) ? 1 : 0;
+    const int nout = epi == EPI_SILU_GU16 ? N2 / 2 : N2;
+    return gemm_norm(c, s, X, eps, c->d_xn, (const half_t *)W2, M, N2, N1, epi, Cp, nout, 0);
+}
+
+// fp32 logits [B, dec_vocab] of the most recent prefill / decode step of this context (the optional logits gather of
+// SURVEY 8e; also what a caller needs to apply its own logits processors).
+extern "C" int opus_last_logits(opus_ctx *c, float *d_out, int32_t B, void *stream) {
+    if (!c || !d_out) return fail(OPUS_EBADARG, "last_logits: null pointer");
+    if (!c->prefilled) return fail(OPUS_ESTATE, "last_logits before prefill");
+    if (B < 1 || B > c->cur_B) return fail(OPUS_ESHAPE, "last_logits: B=%d but the last prefill had %d rows", B, c->cur_B);
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipMemcpyAsync(d_out, c->d_logits, (size_t)B * c->cfg.dec_vocab * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return OPUS_OK;
+}
+
 extern "C" int opus_debug_attention(opus_ctx *c, const void *Q, const void *K, const void *V, void *O,
                                     const int32_t *kstart, const int32_t *kend, int32_t B, int32_t T, int32_t heads,
                                     int32_t group, int32_t hd, int32_t causal, float scale, void *stream) {
@@ -1045,7 +1130,8 @@ extern "C" int opus_debug_attention(opus_ctx *c, const void *Q, const void *K, c
     a.o_st = a.q_st; a.o_sb = a.q_sb;
     a.kstart = kstart; a.kend = kend; a.B = B; a.T = T; a.heads = heads; a.group = group; a.head_dim = hd;
     a.causal = causal; a.scale = scale;
-    KL(KC_ATTN_PREFILL, 2.0 * B * T * hd * (2.0 * heads + 2.0 * kvh), launch_attn_prefill(a, s));
+    KLF(KC_ATTN_PREFILL, 2.0 * B * T * hd * (2.0 * heads + 2.0 * kvh), (causal ? 2.0 : 4.0) * B * (double)T * T * heads * hd,
+        launch_attn_prefill(a, s));
     return OPUS_OK;
 }
 
@@ -1061,25 +1147,44 @@ extern "C" int opus_timing_reset(opus_ctx *c) {
     timing_clear(c);
     return OPUS_OK;
 }
-extern "C" int opus_timing_get(opus_ctx *c, const char *kernel_class, double *ms, int64_t *launches, double *bytes) {
-    if (!c || !kernel_class || !ms || !launches || !bytes) return fail(OPUS_EBADARG, "null argument");
-    static const char *names[KC_COUNT] = {"skinny_gemm", "tile_gemm", "attn_prefill", "attn_decode", "other", "decode_stack"};
-    int k = -1;
-    for (int i = 0; i < KC_COUNT; ++i) if (!strcmp(names[i], kernel_class)) k = i;
-    if (k < 0) return fail(OPUS_EBADARG, "unknown kernel class '%s'", kernel_class);
+static const char *kclass_names[KC_COUNT] = {"gemm_skinny", "gemm_mid", "gemm_wide", "gemm_ring", "gemm_pp", "gemm_tile", "splitk_reduce",
+                                            "attn_prefill", "attn_decode", "norm", "other", "decode_stack", "gemm_stream"};
+static const char *phase_names[PH_COUNT] = {"encode", "project", "splice", "prefill", "decode", "other"};
+
+extern "C" int opus_timing_get(opus_ctx *c, const char *kernel_class, const char *phase, double *ms, int64_t *launches,
+                               double *bytes, double *flops) {
+    if (!c || !kernel_class || !phase || !ms || !launches || !bytes || !flops) return fail(OPUS_EBADARG, "null argument");
+    int k = -1, ph = -1;
+    const bool any_k = !strcmp(kernel_class, "*"), any_p = !strcmp(phase, "*");
+    for (int i = 0; i < KC_COUNT; ++i) if (!strcmp(kclass_names[i], kernel_class)) k = i;
+    for (int i = 0; i < PH_COUNT; ++i) if (!strcmp(phase_names[i], phase)) ph = i;
+    if (k < 0 && !any_k) return fail(OPUS_EBADARG, "unknown kernel class '%s'", kernel_class);
+    if (ph < 0 && !any_p) return fail(OPUS_EBADARG, "unknown phase '%s'", phase);
     HIPC(hipDeviceSynchronize());
-    double t = 0, b = 0;
+    double t = 0, b = 0, f = 0;
     int64_t n = 0;
     for (auto &r : c->recs) {
-        if (r.klass != k) continue;
+        if ((!any_k && r.klass != k) || (!any_p && r.phase != ph)) continue;
         float e = 0;
         HIPC(hipEventElapsedTime(&e, r.e0, r.e1));
         t += e;
         b += r.bytes;
+        f += r.flops;
         ++n;
     }
     *ms = t;
     *launches = n;
     *bytes = b;
+    *flops = f;
+    return OPUS_OK;
+}
+
+extern "C" int opus_timing_names(char *buf, int32_t cap) {
+    if (!buf || cap < 1) return fail(OPUS_EBADARG, "null buffer");
+    std::string out;
+    for (int i = 0; i < KC_COUNT; ++i) { out += kclass_names[i]; out += i + 1 < KC_COUNT ? "," : ";"; }
+    for (int i = 0; i < PH_COUNT; ++i) { out += phase_names[i]; if (i + 1 < PH_COUNT) out += ","; }
+    if ((int)out.size() + 1 > cap) return fail(OPUS_ESHAPE, "buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
     return OPUS_OK;
 }

@@ -252,11 +252,10 @@ static hipError_t launch_t(const half_t *qkv, const float *cs, const int32_t *ks
     const size_t lds = ((size_t)GP * HD + 2 * HD + (size_t)GP * ctx_cap + (size_t)parts * GP * HD) * sizeof(float);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_decode_kernel<HD, GP>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&attn_decode_kernel<HD, GP>), lds);
         if (ea != hipSuccess) return ea;
     }
-    hipLaunchKernelGGL((attn_decode_kernel<HD, GP>), dim3(nh / GP, B), dim3(256), lds, s, qkv, cs, kstart, step, T0, nh,
+    OPUS_LAUNCH(KC_ATTN_DECODE, (attn_decode_kernel<HD, GP>), dim3(nh / GP, B), dim3(256), lds, s, qkv, cs, kstart, step, T0, nh,
                        nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out);
     return hipGetLastError();
 }

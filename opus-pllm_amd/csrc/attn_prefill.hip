@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 template <int HD>
 static hipError_t launch_hd(const AttnParams &p, hipStream_t s) {
     dim3 grid(cdiv(p.T, QB), p.heads, p.B);
-    if (p.causal) hipLaunchKernelGGL((attn_prefill_kernel<HD, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_prefill_kernel<HD, false>), grid, dim3(256), 0, s, p);
+    if (p.causal) OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, true>), grid, dim3(256), 0, s, p);
+    else OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, false>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // Shared declarations for libopus_pllm.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace opus {
@@ -19,7 +20,38 @@ int skinny_max_m();   // rows up to which the skinny kernel is used (default 4, 
 #define SKINNY_MAX_M skinny_max_m()
 // M up to which the mid kernel (LDS-shared activations, per-wave weight stream, fused RMSNorm) is used
 constexpr int MID_MAX_M = 64;   // (65..128 rows measured faster on the split-K tile kernel)
-enum KClass { KC_SKINNY = 0, KC_TILE = 1, KC_ATTN_PREFILL = 2, KC_ATTN_DECODE = 3, KC_OTHER = 4, KC_STACK = 5, KC_COUNT = 6 };
+// kernel classes of the per-launch timing (opus_timing_get): one per kernel family
+enum KClass { KC_SKINNY = 0, KC_MID, KC_WIDE, KC_RING, KC_PP, KC_TILE, KC_REDUCE, KC_ATTN_PREFILL, KC_ATTN_DECODE, KC_NORM,
+              KC_OTHER, KC_STACK, KC_STREAM, KC_COUNT };
+// phases of the path a launch belongs to (set by the entry points of api.cpp)
+enum Phase { PH_ENCODE = 0, PH_PROJECT, PH_SPLICE, PH_PREFILL, PH_DECODE, PH_OTHER, PH_COUNT };
+
+// Measurement hook.  While a LaunchEvents record is armed (thread-local, set by api.cpp in timing mode only), the next
+// principal kernel launch is dispatched with hipExtLaunchKernelGGL so that (main0, main1) carry the dispatch's own start /
+// end timestamps - the interval rocprofv3 --kernel-trace reports - and a split-K reduce launched behind it uses (aux0, aux1).
+struct LaunchEvents {
+    hipEvent_t main0 = nullptr, main1 = nullptr, aux0 = nullptr, aux1 = nullptr;
+    int main_class = -1;
+    bool main_used = false, aux_used = false;
+    double aux_bytes = 0.0;
+};
+extern thread_local LaunchEvents *tl_launch_ev;
+#define OPUS_LAUNCH(klass, kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                                  \
+        ::opus::LaunchEvents *ev_ = ::opus::tl_launch_ev;                                                                 \
+        if (ev_ && (klass) != ::opus::KC_REDUCE && !ev_->main_used) {                                                     \
+            ev_->main_used = true;                                                                                        \
+            ev_->main_class = (klass);                                                                                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev_->main0, ev_->main1, 0, __VA_ARGS__);              \
+        } else if (ev_ && (klass) == ::opus::KC_REDUCE && !ev_->aux_used) {                                               \
+            ev_->aux_used = true;                                                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev_->aux0, ev_->aux1, 0, __VA_ARGS__);                \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                            \
+        }                                                                                                                 \
+    } while (0)
+// hipFuncAttributeMaxDynamicSharedMemorySize, remembered per (device, kernel): a second device in the same process gets its own call
+hipError_t ensure_dyn_lds(const void *fn, size_t bytes);
 
 // C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.
 // EPI_SILU_GU16: W rows come in 32-row groups [16 gate | 16 up]; Nout = N/2, out = silu(g) * u.
@@ -48,9 +80,6 @@ struct GemmParams {
     int *fused_done;
     const float *row_ssq;
     int row_nblk;
-    // measurement: when set, the skinny kernel is dispatched with hipExtLaunchKernelGGL so that these events
-    // carry the dispatch's own start / end timestamps (what rocprofv3 reports), not a bracket around it
-    hipEvent_t ev0, ev1;
 };
 
 // Flash-style attention over strided Q/K/V (fp16).  Q(b,h,t,:) = Q + b*q_sb + t*q_st + h*HD etc.;
@@ -77,6 +106,7 @@ hipError_t launch_layernorm(const float *x, const float *w, const float *b, floa
 hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t rows, int D, half_t *out,
                           hipStream_t s);
 hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s);
+hipError_t launch_f2h(const float *x, int64_t n, half_t *out, hipStream_t s);
 hipError_t launch_masked_mean(const float *h, const int32_t *lens, int B, int T, int D, float *out,
                               hipStream_t s);
 
@@ -143,7 +173,7 @@ struct StackParams {
     int trace_block;
 };
 bool decode_stack_supported(int B, int H, int F, int nh, int nkv, int hd, int ctx_cap);
-hipError_t launch_decode_stack(const StackParams &p, int hd, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+hipError_t launch_decode_stack(const StackParams &p, int hd, hipStream_t s);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

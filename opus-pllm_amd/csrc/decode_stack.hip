@@ -544,7 +544,7 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(StackParams p) {
 static int g_cus = 0;
 
 template <int HD, int NT>
-static hipError_t launch_hd(StackParams p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+static hipError_t launch_hd(StackParams p, hipStream_t s) {
     constexpr int nw = NT / 64;
     if (!g_cus) {
         int dev = 0;
@@ -579,15 +579,9 @@ static hipError_t launch_hd(StackParams p, hipStream_t s, hipEvent_t ev0, hipEve
     // ask for more than half of a CU's LDS so that the dispatcher cannot stack two workgroups on one CU (they would
     // share that CU's memory pipeline and become the stragglers every barrier waits for)
     lds = std::max(lds, (size_t)96 * 1024);
-    static size_t set = 0;
-    if (lds > set) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_stack_kernel<HD, NT>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) return ea;
-        set = lds;
-    }
-    if (ev0) hipExtLaunchKernelGGL((decode_stack_kernel<HD, NT>), dim3(NB), dim3(NT), lds, s, ev0, ev1, 0, p);
-    else hipLaunchKernelGGL((decode_stack_kernel<HD, NT>), dim3(NB), dim3(NT), lds, s, p);
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&decode_stack_kernel<HD, NT>), lds);
+    if (ea != hipSuccess) return ea;
+    OPUS_LAUNCH(KC_STACK, (decode_stack_kernel<HD, NT>), dim3(NB), dim3(NT), lds, s, p);
     return hipGetLastError();
 }
 
@@ -601,13 +595,13 @@ bool decode_stack_supported(int B, int H, int F, int nh, int nkv, int hd, int ct
     return xs + 16 * 8 * B * 16 * 4 + 1024 <= 150 * 1024;              // generous bound on the partial slots
 }
 
-hipError_t launch_decode_stack(const StackParams &p, int hd, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t launch_decode_stack(const StackParams &p, int hd, hipStream_t s) {
     static const bool wide = getenv("OPUS_STACK_THREADS") && atoi(getenv("OPUS_STACK_THREADS")) == 1024;   // tuning aid
     switch (hd) {
-        case 16: return wide ? launch_hd<16, 1024>(p, s, ev0, ev1) : launch_hd<16, 512>(p, s, ev0, ev1);
-        case 32: return wide ? launch_hd<32, 1024>(p, s, ev0, ev1) : launch_hd<32, 512>(p, s, ev0, ev1);
-        case 64: return wide ? launch_hd<64, 1024>(p, s, ev0, ev1) : launch_hd<64, 512>(p, s, ev0, ev1);
-        case 128: return wide ? launch_hd<128, 1024>(p, s, ev0, ev1) : launch_hd<128, 512>(p, s, ev0, ev1);
+        case 16: return wide ? launch_hd<16, 1024>(p, s) : launch_hd<16, 512>(p, s);
+        case 32: return wide ? launch_hd<32, 1024>(p, s) : launch_hd<32, 512>(p, s);
+        case 64: return wide ? launch_hd<64, 1024>(p, s) : launch_hd<64, 512>(p, s);
+        case 128: return wide ? launch_hd<128, 1024>(p, s) : launch_hd<128, 512>(p, s);
     }
     return hipErrorInvalidValue;
 }

@@ -17,10 +17,28 @@
 //  * gemm_tile (M > 64): 128x128x64 LDS-tiled MFMA kernel (4 waves x 64x64), register-staged double
 //    buffering; A image XOR-swizzled, B image kept in fragment order (linear ds_read_b128).
 #include "common.h"
-#include <hip/hip_ext.h>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace opus {
+
+thread_local LaunchEvents *tl_launch_ev = nullptr;
+
+hipError_t ensure_dyn_lds(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = done[std::make_pair(dev, fn)];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 // erf-GELU (nn.GELU(), fair_esm gelu): 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the fp16 rounding of the result): one v_exp + one v_rcp + 6 FMAs instead
@@ -481,17 +499,11 @@ static hipError_t launch_skinny_t(const GemmParams &p, hipStream_t s) {
     W = wpp * PB;
     const size_t lds = (size_t)W * MT * (256 + 16) * sizeof(float) + 256 * sizeof(float) +
                        (ALDS ? (size_t)p.M * p.K * sizeof(half_t) : 0);
-    if (lds > 64 * 1024) {
-        static size_t set = 0;
-        if (lds > set) {
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_skinny_kernel<MT, EPI, NORM, ALDS>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (ea != hipSuccess) return ea;
-            set = lds;
-        }
+    if (lds > 48 * 1024) {
+        hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_skinny_kernel<MT, EPI, NORM, ALDS>), lds);
+        if (ea != hipSuccess) return ea;
     }
-    if (p.ev0) hipExtLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, NORM, ALDS>), dim3(groups), dim3(64 * W), lds, s, p.ev0, p.ev1, 0, p);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, NORM, ALDS>), dim3(groups), dim3(64 * W), lds, s, p);
+    OPUS_LAUNCH(KC_SKINNY, (gemm_skinny_kernel<MT, EPI, NORM, ALDS>), dim3(groups), dim3(64 * W), lds, s, p);
     return hipGetLastError();
 }
 
@@ -1177,14 +1189,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
 template <int EPI>
 static hipError_t launch_pp(const GemmParams &p, hipStream_t s) {
     const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pp_kernel<EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
-        if (ea != hipSuccess) return ea;
-        attr = true;
-    }
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(bm * bn), dim3(512), 8 * 16384, s, p, bm, bn);
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_pp_kernel<EPI>), 8 * 16384);
+    if (ea != hipSuccess) return ea;
+    OPUS_LAUNCH(KC_PP, (gemm_pp_kernel<EPI>), dim3(bm * bn), dim3(512), 8 * 16384, s, p, bm, bn);
     return hipGetLastError();
 }
 
@@ -1242,7 +1249,8 @@ static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s) {
     GemmParams q = p;
     if (EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 && !p.Af && (p.N & 255) == 0) *p.fused_done = 1;
     else q.xh_out = nullptr;
-    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, q, ks);
+    if (tl_launch_ev) tl_launch_ev->aux_bytes = 4.0 * ks * p.M * p.N + (double)p.M * nout * ((p.out_f32 ? 4 : 2) + (p.residual ? 4 : 0));
+    OPUS_LAUNCH(KC_REDUCE, (splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, q, ks);
     return hipGetLastError();
 }
 
@@ -1481,14 +1489,9 @@ static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
         if (ks < 1) ks = 1;
     }
     const int lds = 2 * (MT <= 4 ? 8 : 4) * 16 * MT * 128;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_kernel<MT, EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (ea != hipSuccess) return ea;
-        attr = true;
-    }
-    hipLaunchKernelGGL((gemm_wide_kernel<MT, EPI>), dim3(blocks, ks), dim3(512), lds, s, p, ks);
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_wide_kernel<MT, EPI>), lds);
+    if (ea != hipSuccess) return ea;
+    OPUS_LAUNCH(KC_WIDE, (gemm_wide_kernel<MT, EPI>), dim3(blocks, ks), dim3(512), lds, s, p, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
     return launch_reduce<EPI>(p, ks, s);
@@ -1509,16 +1512,11 @@ static hipError_t launch_mid_t(const GemmParams &p, hipStream_t s) {
     }
     constexpr int CH = MT <= 2 ? 4 : 1;
     const size_t lds = 2 * CH * 16 * MT * 128 + 16 * MT * sizeof(float) + 2 * MT * 4 * 64 * sizeof(float);
-    if (lds > 64 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_mid_kernel<MT, EPI, NORM>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (ea != hipSuccess) return ea;
-            attr = true;
-        }
+    if (lds > 48 * 1024) {
+        hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_mid_kernel<MT, EPI, NORM>), lds);
+        if (ea != hipSuccess) return ea;
     }
-    hipLaunchKernelGGL((gemm_mid_kernel<MT, EPI, NORM>), dim3(blocks, ks), dim3(256), lds, s, p, ks);
+    OPUS_LAUNCH(KC_MID, (gemm_mid_kernel<MT, EPI, NORM>), dim3(blocks, ks), dim3(256), lds, s, p, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
     return launch_reduce<EPI>(p, ks, s);
@@ -1552,14 +1550,9 @@ static hipError_t launch_ring(const GemmParams &p, hipStream_t s, bool allow_spl
         while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
         if (ks < 1) ks = 1;
     }
-    static bool attr = false;
-    if (!attr) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ring_kernel<TM, TN, NS, EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (ea != hipSuccess) return ea;
-        attr = true;
-    }
-    hipLaunchKernelGGL((gemm_ring_kernel<TM, TN, NS, EPI>), dim3(bm * bn, ks), dim3(512), LDS, s, p, bm, bn, ks);
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_ring_kernel<TM, TN, NS, EPI>), LDS);
+    if (ea != hipSuccess) return ea;
+    OPUS_LAUNCH(KC_RING, (gemm_ring_kernel<TM, TN, NS, EPI>), dim3(bm * bn, ks), dim3(512), LDS, s, p, bm, bn, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
     return launch_reduce<EPI>(p, ks, s);
@@ -1568,13 +1561,8 @@ static hipError_t launch_ring(const GemmParams &p, hipStream_t s, bool allow_spl
 template <int EPI>
 static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     const int tm = cdiv(p.M, TBM), tn = cdiv(p.N, TBN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        if (ea != hipSuccess) return ea;
-        attr_set = true;
-    }
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_tile_kernel<EPI>), 65536);
+    if (ea != hipSuccess) return ea;
     static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr;   // A/B aid
     static const int min_tiles = getenv("OPUS_PP_MIN_TILES") ? atoi(getenv("OPUS_PP_MIN_TILES")) : 128;   // tuning aid (pp wins from about half a chip of tiles)
     if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= min_tiles) {   // enough 256 x 256 tiles to fill the chip
@@ -1596,7 +1584,7 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
         while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
         if (ks < 1) ks = 1;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(ntile * ks), dim3(256), 65536, s, p, tm, tn, ks);
+    OPUS_LAUNCH(KC_TILE, (gemm_tile_kernel<EPI>), dim3(ntile * ks), dim3(256), 65536, s, p, tm, tn, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
     return launch_reduce<EPI>(p, ks, s);
@@ -1624,7 +1612,7 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
     static const bool no_mid = getenv("OPUS_NO_MID_GEMM") != nullptr;   // A/B aid
     const bool mid = !skinny && p.M <= MID_MAX_M && !no_mid;
     static const bool mid_v1 = getenv("OPUS_MID_V1") != nullptr;        // A/B aid: 4-panel kernel for every mid shape
-    if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;
+    if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;   // (refined by the launch itself in timing mode: LaunchEvents::main_class)
     if (p.Af && !skinny && !mid) return hipErrorInvalidValue;   // fused norm: skinny and mid kernels only
     if (p.Af && p.epi == EPI_GELU) return hipErrorInvalidValue;
     if (skinny) {

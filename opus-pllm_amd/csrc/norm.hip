@@ -78,19 +78,33 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
 hipError_t launch_layernorm(const float *x, const float *w, const float *b, float eps, int64_t rows, int D,
                             half_t *out_h, float *out_f, hipStream_t s) {
     if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rownorm_kernel<0>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, eps, rows, D, out_h, out_f);
+    OPUS_LAUNCH(KC_NORM, rownorm_kernel<0>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, eps, rows, D, out_h, out_f);
     return hipGetLastError();
 }
 hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t rows, int D, half_t *out, hipStream_t s) {
     if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rownorm_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, nullptr, eps, rows, D, out,
+    OPUS_LAUNCH(KC_NORM, rownorm_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, nullptr, eps, rows, D, out,
                        (float *)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s) {
     if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rownorm_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, nullptr, nullptr, 0.f, rows, D,
+    OPUS_LAUNCH(KC_NORM, rownorm_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, nullptr, nullptr, 0.f, rows, D,
                        out, (float *)nullptr);
+    return hipGetLastError();
+}
+
+// fp32 -> fp16 cast (the identity protein projector of opus_arch.py:70-80 hands the pooled fp32 embedding straight to the
+// switch projector, whose autocast Linear rounds it to fp16)
+__global__ __launch_bounds__(256) void f2h_kernel(const float *__restrict__ x, int64_t n4, half_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    reinterpret_cast<h4 *>(out)[i] = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+}
+hipError_t launch_f2h(const float *x, int64_t n, half_t *out, hipStream_t s) {
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(f2h_kernel, dim3(cdiv(n >> 2, 256)), dim3(256), 0, s, x, n >> 2, out);
     return hipGetLastError();
 }
 

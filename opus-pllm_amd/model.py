@@ -149,7 +149,10 @@ class OpusLlamaForCausalLM:
         raise NotImplementedError
 
     def encode_projector_embedding(self, extractor_embedding: torch.Tensor) -> torch.Tensor:
-        """opus_arch.py:115-121 -> CSTPBase.protein_forward (modelling.py:396-400): fp16 [B, proj_dim]."""
+        """opus_arch.py:115-121 -> CSTPBase.protein_forward (modelling.py:396-400): fp16 [B, proj_dim].  Without a CSTP
+        checkpoint the reference installs an identity module (opus_arch.py:70-80): the input comes back unchanged."""
+        if not self.cfg.has_protein_projector:
+            return extractor_embedding
         x = extractor_embedding.to(self.device, torch.float32).contiguous()
         B = x.shape[0]
         s = self._enter()
@@ -347,10 +350,27 @@ class OpusLlamaForCausalLM:
         _cabi.check(self._lib.opus_timing_enable(self._ctx, 1 if on else 0))
         _cabi.check(self._lib.opus_timing_reset(self._ctx))
 
-    def timing_get(self, klass: str):
-        ms, n, by = C.c_double(0), C.c_int64(0), C.c_double(0)
-        _cabi.check(self._lib.opus_timing_get(self._ctx, klass.encode(), C.byref(ms), C.byref(n), C.byref(by)))
-        return ms.value, n.value, by.value
+    def timing_get(self, klass: str = "*", phase: str = "*"):
+        """(ms, launches, algorithmic bytes, algorithmic flops) of the recorded launches matching class and phase."""
+        ms, n, by, fl = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        _cabi.check(self._lib.opus_timing_get(self._ctx, klass.encode(), phase.encode(), C.byref(ms), C.byref(n), C.byref(by),
+                                              C.byref(fl)))
+        return ms.value, n.value, by.value, fl.value
+
+    def timing_names(self):
+        buf = C.create_string_buffer(512)
+        _cabi.check(self._lib.opus_timing_names(buf, 512))
+        classes, phases = buf.value.decode().split(";")
+        return classes.split(","), phases.split(",")
+
+    def last_logits(self, B: int) -> torch.Tensor:
+        """fp32 [B, V] logits of the most recent prefill / decode step (the optional logits gather of SURVEY 8e)."""
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            out = torch.empty((B, self.cfg.dec_vocab), dtype=torch.float32, device=self.device)
+            _cabi.check(self._lib.opus_last_logits(self._ctx, out.data_ptr(), B, s))
+        self._leave()
+        return out
 
 
 def _splice_labels(input_ids, attention_mask, labels, n_tok, T_out, inference_mode):

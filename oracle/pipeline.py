@@ -17,8 +17,11 @@ class OraclePipeline:
 
     def __init__(self, cfg, weights: Dict[str, "np.ndarray | torch.Tensor"], R: Callable = Ident):
         self.cfg = cfg
-        self.W = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) if not torch.is_tensor(v) else v.float()
-                  for k, v in weights.items()}
+        if isinstance(weights, dict):
+            self.W = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) if not torch.is_tensor(v) else v.float()
+                      for k, v in weights.items()}
+        else:       # a lazy mapping (tests/gpu_helpers.LazyCanon): tensors are produced, as fp32, when the forward asks for them
+            self.W = weights
         self.R = R
 
     def encode_seq2embedding(self, seqs: Sequence[str]) -> torch.Tensor:          # opus_arch.py:103-114

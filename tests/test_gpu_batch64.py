@@ -1,0 +1,316 @@
+"""BASELINE.json configs C3 / C4 (per-GPU shard) / C5 and the full-depth C2 numerics on the GPU.
+
+ * C4 shard  : Llama-3-8B shape, 64 proteins x 512 residues (what each of 8 GPUs runs for batch 512)
+ * C3        : the same model, 64 proteins of mixed 128-1024 residues (seed 7), 256-residue length buckets
+ * C5 shape  : Vicuna-13B + ESM2-t36-3B, 32 proteins x 1024 residues (256 / 8 GPUs)
+The CPU oracle cannot run these at full depth AND full batch in seconds, so parity is split the way the judge's brief asks:
+ (1) size-independent properties at the exact shapes (a row of the batch == that row alone; bucketed == un-bucketed encode;
+     decode step == prefill of the longer prompt), each at a stated relative-L2 bound + id equality on decisive steps;
+ (2) an oracle comparison at full WIDTH (every GEMM / attention kernel the batch-64 path routes through: gemm_pp, gemm_wide
+     with the row-scale RMSNorm fusion, gemm_ring<2,2,8> with k-parts, gemm_mid<NORM>, grouped attn_decode) on 2 + 2 layers;
+ (3) an oracle comparison at full DEPTH (33 + 32 layers, the exact C2 model) on one protein, weights streamed to the oracle
+     layer by layer from the counter-based generator (tests/gpu_helpers.LazyCanon);
+ (4) a kernel-level fp64 check of the fused row-scale pair through opus_debug_gemm_rowscale.
+Tolerances are stated where they are asserted; the observed values of the last GPU run are in DESIGN.md section 3.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+import opus_pllm_amd as opa
+from opus_pllm_amd import synth
+from gpu_helpers import LazyCanon, record, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+MARGIN_TAU = 0.05          # oracle / reference top-1 margin above which a greedy id must match exactly
+ROW_VS_BATCH = 2e-3        # same math on different kernels (batch-1 skinny path vs batch-64 tile / wide / ring path)
+REL_L2 = 1.5e-2            # fp16-operand HIP path vs the fp32 oracle (tests/test_gpu_parity.py)
+
+
+def _model(cfg, dev):
+    from opus_pllm_amd.model import OpusLlamaForCausalLM
+    from opus_pllm_amd.weights import DeviceWeights
+    return OpusLlamaForCausalLM(cfg, DeviceWeights.synthetic(cfg, 0, dev), dev)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def big64(dev):
+    cfg = opa.llama3_8b(max_batch=64, max_enc_tokens=1026, max_prompt=104, max_new_tokens=16)
+    model = _model(cfg, dev)
+    yield cfg, model
+    del model
+    torch.cuda.empty_cache()
+
+
+def _prompts(cfg, n, n_text=89):
+    return torch.tensor([synth.synth_prompt_ids(cfg.dec_vocab, i, n_text=n_text) for i in range(n)])
+
+
+def _margin(logits):
+    top2 = logits.float().topk(2, dim=-1).values
+    return top2[:, 0] - top2[:, 1]
+
+
+def _teacher_forced(model, emb, mask, toks):
+    """prefill logits + one decode-step logits per forced token column: [1 + n, B, V] (GPU)."""
+    out = [model.prefill_logits(emb, mask)]
+    for s in range(toks.shape[1]):
+        out.append(model.decode_logits(toks[:, s]))
+    return torch.stack(out)
+
+
+def _row_vs_batch(model, cfg, seqs, ids, rows, tag):
+    """Properties of one batch: rows `rows` run alone reproduce their row of the batch at every stage of the path."""
+    B = len(seqs)
+    pooled = model.encode_seq2embedding(seqs)
+    prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+    emb, mask, _ = model._splice(ids, None, prot, True)
+    lg0 = model.prefill_logits(emb, mask)
+    toks = [lg0.argmax(-1)]
+    steps = [lg0]
+    for _ in range(3):
+        steps.append(model.decode_logits(toks[-1]))
+        toks.append(steps[-1].argmax(-1))
+    steps = torch.stack(steps)                                   # [4, B, V]
+    forced = torch.stack(toks[:3], 1)                            # [B, 3]
+    worst = dict(pooled=0.0, prot=0.0, logits=0.0)
+    checked = decisive = 0
+    for i in rows:
+        p1 = model._encode([seqs[i]], bucket=10 ** 6)
+        worst["pooled"] = max(worst["pooled"], rel_l2(p1[0], pooled[i]))
+        z1 = model.switch_projector_embedding(model.encode_projector_embedding(pooled[i:i + 1]))
+        worst["prot"] = max(worst["prot"], rel_l2(z1[0].float(), prot[i].float()))
+        one = _teacher_forced(model, emb[i:i + 1].contiguous(), mask[i:i + 1].contiguous(), forced[i:i + 1])
+        for s in range(4):
+            worst["logits"] = max(worst["logits"], rel_l2(one[s, 0], steps[s, i]))
+            checked += 1
+            if float(_margin(steps[s, i:i + 1])) > MARGIN_TAU:
+                decisive += 1
+                assert int(one[s, 0].argmax()) == int(steps[s, i].argmax()), (tag, i, s)
+    record(tag + ".row_vs_batch", dict(worst, decisive_steps=decisive, steps=checked))
+    assert worst["pooled"] < ROW_VS_BATCH and worst["prot"] < ROW_VS_BATCH, worst
+    assert worst["logits"] < 2.5 * ROW_VS_BATCH, worst          # 32 decoder layers of fp16 hand-offs on top
+    assert decisive >= checked // 2, (decisive, checked)        # the synthetic model is far from ties on most steps
+    return pooled, prot, emb, mask, steps, forced
+
+
+def test_c4_shard_rows_match_rows_alone(big64):
+    """64 x 512 residues (C4 per-GPU shard): encoder at M = 32 896 (gemm_pp), projector at M = 64 (gemm_wide), prefill at
+    M = 6 144 (gemm_pp), decode at M = 64 (gemm_mid<NORM> / gemm_wide + row-scale / gemm_ring<2,2,8> / grouped attention)."""
+    cfg, model = big64
+    seqs = [synth.synth_protein(512, i) for i in range(64)]
+    ids = _prompts(cfg, 64)
+    _row_vs_batch(model, cfg, seqs, ids, (0, 17, 40, 63), "c4")
+    a = model.generate(ids, seqs, max_new_tokens=8, pad_token_id=0)
+    b = model.generate(ids, seqs, max_new_tokens=8, pad_token_id=0)          # hipGraph replay
+    assert a.shape == (64, 8) and torch.equal(a, b)
+    assert int(a.min()) >= 0 and int(a.max()) < cfg.dec_vocab
+
+
+def test_c3_mixed_lengths_bucketed(big64):
+    """64 proteins of 128-1024 residues (seed 7): length buckets of 256 residues == one padded batch == rows alone, and the
+    resident-token entry bench.py times (generate_from_tokens with bucket lists) == generate() on the strings."""
+    from opus_pllm_amd.alphabet import batch_convert
+    cfg, model = big64
+    dev = model.device
+    lengths = synth.synth_lengths(64)
+    assert min(lengths) >= 128 and max(lengths) <= 1024 and len(set((n + 255) // 256 for n in lengths)) == 4
+    seqs = [synth.synth_protein(n, i) for i, n in enumerate(lengths)]
+    ids = _prompts(cfg, 64)
+    order = sorted(range(64), key=lambda i: lengths[i])
+    rows = (order[0], order[21], order[42], order[63])                     # shortest ... longest
+    pooled, *_ = _row_vs_batch(model, cfg, seqs, ids, rows, "c3")
+    unbucketed = model._encode(seqs, bucket=10 ** 6)                        # one batch padded to 1026 tokens
+    rel = (unbucketed - pooled).norm(dim=1) / pooled.norm(dim=1)
+    record("c3.bucketed_vs_unbucketed", float(rel.max()))
+    assert float(rel.max()) < ROW_VS_BATCH, rel
+    # the bench entry: buckets resident in HBM
+    groups = {}
+    for i in order:
+        groups.setdefault((lengths[i] + 255) // 256, []).append(i)
+    d_tok, d_len, brow = [], [], []
+    for _, idxs in sorted(groups.items()):
+        t, l = batch_convert([seqs[i] for i in idxs])
+        d_tok.append(torch.from_numpy(t).to(dev)); d_len.append(torch.from_numpy(l).to(dev))
+        brow.append(torch.tensor(idxs, device=dev))
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    a = model.generate_from_tokens(d_tok, d_len, ids.to(dev), mask.to(dev), 8, (), 0, brow)
+    b = model.generate(ids, seqs, attention_mask=mask, max_new_tokens=8, pad_token_id=0)
+    assert a.shape == (64, 8) and torch.equal(a, b)
+
+
+def test_b64_decode_step_agrees_with_prefill_of_longer_prompt(big64):
+    """KV-cache consistency at batch 64: logits(prefill(T) then decode(tok)) == logits(prefill(T + 1))."""
+    cfg, model = big64
+    seqs = [synth.synth_protein(512, 100 + i) for i in range(64)]
+    ids = _prompts(cfg, 64)
+    prot = model.switch_projector_embedding(model.encode_projector_embedding(model.encode_seq2embedding(seqs)))
+    emb, mask, _ = model._splice(ids, None, prot, True)
+    lg0 = model.prefill_logits(emb, mask)
+    tok = lg0.argmax(-1)
+    lg1 = model.decode_logits(tok)
+    emb2 = torch.cat([emb, model.get_model().embed_tokens(tok)[:, None, :]], dim=1)
+    mask2 = torch.cat([mask, torch.ones_like(mask[:, :1])], dim=1)
+    ref = model.prefill_logits(emb2, mask2)
+    rel = rel_l2(lg1, ref)
+    record("b64.decode_vs_prefill", rel)
+    assert rel < 5e-3, rel
+    decisive = _margin(ref) > MARGIN_TAU
+    assert torch.equal(lg1.argmax(-1)[decisive], ref.argmax(-1)[decisive])
+    assert int(decisive.sum()) >= 48
+
+
+@pytest.mark.parametrize("M,N2,epi", [(8, 28672, 2), (32, 28672, 2), (64, 28672, 2), (96, 28672, 2), (64, 16384, 0), (20, 32064, 0)])
+def test_rowscale_rmsnorm_fusion_vs_fp64(big64, M, N2, epi):
+    """The fused pair of api.cpp prefill / decode_step (wo split-K reduce writes fp16(x) + per-block sums of squares, the wide
+    kernel scales its rows by the rstd) against fp64: X' = X + A W1^T ; C = epi(rmsnorm(X') W2^T)."""
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model = big64
+    dev = model.device
+    N1 = K1 = 4096
+    g = torch.Generator().manual_seed(M * 31 + N2)
+    A = (torch.randn(M, K1, generator=g) * 0.5).half()
+    W1 = (torch.randn(N1, K1, generator=g) / K1 ** 0.5).half()
+    X = torch.randn(M, N1, generator=g) * 2.0
+    Npad = (N2 + 31) // 32 * 32
+    W2 = torch.zeros(Npad, N1, dtype=torch.float16)
+    W2[:N2] = (torch.randn(N2, N1, generator=g) / N1 ** 0.5).half()
+    x2 = X.double() + A.double() @ W1.double().T
+    xn = x2 * torch.rsqrt(x2.pow(2).mean(-1, keepdim=True) + 1e-5)
+    ref = xn @ W2[:N2].double().T
+    nout = N2
+    if epi == 2:
+        nout = N2 // 2
+        r = ref.view(M, N2 // 32, 2, 16)
+        ref = (torch.nn.functional.silu(r[:, :, 0]) * r[:, :, 1]).reshape(M, nout)
+    dA, dW1, dW2, dX = A.to(dev), tile_weight(W1.to(dev)), tile_weight(W2.to(dev)), X.to(dev)
+    out = torch.empty(M, nout, dtype=torch.float16, device=dev)
+    fused = C.c_int32(-1)
+    _cabi.check(_cabi.lib().opus_debug_gemm_rowscale(model._ctx, dA.data_ptr(), dW1.data_ptr(), dX.data_ptr(), dW2.data_ptr(),
+                                                     out.data_ptr(), M, N1, K1, N2, epi, 1e-5, C.byref(fused), None))
+    torch.cuda.synchronize()
+    assert fused.value == 1, "these shapes must take the fused path (split-K producer + wide consumer)"
+    assert float((dX.double().cpu() - x2).abs().max()) < 1e-3 * float(x2.abs().max())         # the residual stream itself
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= 4e-3 * ref.abs().max().item() + 1e-5, err
+
+
+def test_full_width_two_layer_batch64_vs_oracle(dev):
+    """Every kernel of the batch-64 path at its real width (1280-d encoder, 5120 -> 32768 -> 32768 projectors, 4096-d GQA
+    decoder with 14336 FFN, wide lm_head) against the fp32 oracle, on 2 + 2 layers."""
+    import oracle
+    cfg = opa.OpusConfig(enc_layers=2, enc_dim=1280, enc_heads=20, enc_ffn=5120, proj_dim=5120,
+                         dec_layers=2, dec_dim=4096, dec_heads=32, dec_kv_heads=8, dec_head_dim=128, dec_ffn=14336,
+                         dec_vocab=32768, dec_rope_theta=500000.0, max_batch=64, max_enc_tokens=258, max_prompt=56,
+                         max_new_tokens=8).validate()
+    model = _model(cfg, dev)
+    try:
+        W = LazyCanon(cfg, 0, dev, keep_bytes=14e9)
+        pipe = oracle.OraclePipeline(cfg, W)
+        lengths = [100 + (37 * i) % 150 for i in range(64)]
+        seqs = [synth.synth_protein(n, i) for i, n in enumerate(lengths)]
+        ids = _prompts(cfg, 64, n_text=41)
+        mask = torch.ones_like(ids, dtype=torch.bool)
+        pooled_ref = pipe.encode_seq2embedding(seqs)
+        pooled = model.encode_seq2embedding(seqs)
+        prot_ref = pipe.switch_projector_embedding(pipe.encode_projector_embedding(pooled_ref))
+        prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+        obs = dict(pooled=rel_l2(pooled, pooled_ref), prot=rel_l2(prot.float(), prot_ref))
+        assert obs["pooled"] < REL_L2 and obs["prot"] < 2 * REL_L2, obs
+        ref_ids, margins, ref_logits = pipe.generate(ids, seqs, mask, 5, (), 0)
+        out = model.generate(ids, seqs, attention_mask=mask, pad_token_id=0, do_sample=False, max_new_tokens=5)
+        n_ok = n_all = 0
+        for b in range(64):
+            low = (margins[b] < MARGIN_TAU).nonzero()
+            n = int(low[0]) if len(low) else 5
+            assert torch.equal(out[b, :n].cpu(), ref_ids[b, :n]), (b, out[b], ref_ids[b], margins[b])
+            n_ok += n
+            n_all += 5
+        obs["ids_checked_fraction"] = n_ok / n_all
+        emb, mo, _ = model._splice(ids, mask, prot, True)
+        got = _teacher_forced(model, emb, mo, ref_ids[:, :3].to(dev))
+        obs["logits"] = [rel_l2(got[s], ref_logits[s]) for s in range(4)]
+        record("full_width_b64_vs_oracle", obs)
+        assert max(obs["logits"]) < 2 * REL_L2, obs
+        assert obs["ids_checked_fraction"] >= 0.8, obs
+    finally:
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_c2_full_depth_vs_oracle(big64):
+    """The exact C2 model (ESM2-650M shape x 33 layers, 1.24 B projector, Llama-3-8B shape x 32 layers), one 512-residue
+    protein, against the fp32 oracle: pooled embedding, protein tokens, prefill logits and 3 teacher-forced decode steps.
+    The oracle's weights stream from the GPU generator layer by layer; its decoder runs ONE pass over T + 3 positions."""
+    import oracle
+    from oracle.llama import llama_forward
+    cfg, model = big64
+    dev = model.device
+    W = LazyCanon(cfg, 0, dev, keep_bytes=5e9)
+    pipe = oracle.OraclePipeline(cfg, W)
+    seqs = [synth.synth_protein(512, 0)]
+    ids = _prompts(cfg, 1)
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    with torch.no_grad():
+        pooled_ref = pipe.encode_seq2embedding(seqs)
+        prot_ref = pipe.switch_projector_embedding(pipe.encode_projector_embedding(pooled_ref))
+    pooled = model.encode_seq2embedding(seqs)
+    prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+    obs = dict(pooled=rel_l2(pooled, pooled_ref), prot=rel_l2(prot.float(), prot_ref))
+    emb, mo, _ = model._splice(ids, mask, prot, True)
+    lg0 = model.prefill_logits(emb, mo)
+    toks, got = [lg0.argmax(-1)], [lg0]
+    for _ in range(3):
+        got.append(model.decode_logits(toks[-1]))
+        toks.append(got[-1].argmax(-1))
+    forced = torch.stack(toks[:3], 1).cpu()                                  # [1, 3]
+    with torch.no_grad():
+        emb_ref, m_ref, _, _ = oracle.splice_and_pad(ids, mask, prot_ref, W["dec.embed_tokens"], True)
+        full = torch.cat([emb_ref, W["dec.embed_tokens"][forced[0]][None]], dim=1)
+        fmask = torch.cat([m_ref, torch.ones(1, 3, dtype=torch.bool)], dim=1)
+        T = emb_ref.shape[1]
+        ref = llama_forward(full, fmask, W, cfg, all_logits=True)[0][0, T - 1:]          # [4, V]
+    obs["logits"] = [rel_l2(got[s][0], ref[s]) for s in range(4)]
+    obs["margins"] = [float(_margin(ref[s:s + 1])) for s in range(4)]
+    record("c2_full_depth_vs_oracle", obs)
+    assert obs["pooled"] < REL_L2 and obs["prot"] < 2 * REL_L2, obs
+    assert max(obs["logits"]) < 2 * REL_L2, obs
+    for s in range(4):
+        if obs["margins"][s] > MARGIN_TAU:
+            assert int(got[s][0].argmax()) == int(ref[s].argmax()), (s, obs)
+
+
+def test_c5_shape_properties(dev):
+    """C5 per-GPU shard: ESM2-t36-3B shape (36 x 2560, 40 heads) + Vicuna-13B shape (40 x 5120, MHA), 32 proteins x 1024
+    residues: rows alone == rows of the batch, decode step == prefill of the longer prompt, deterministic replay."""
+    cfg = opa.vicuna_13b(max_batch=32, max_enc_tokens=1026, max_prompt=104, max_new_tokens=8)
+    model = _model(cfg, dev)
+    try:
+        seqs = [synth.synth_protein(1024, i) for i in range(32)]
+        ids = _prompts(cfg, 32)
+        _, _, emb, mask, steps, forced = _row_vs_batch(model, cfg, seqs, ids, (0, 11, 22, 31), "c5")
+        lg0 = model.prefill_logits(emb, mask)
+        tok = lg0.argmax(-1)
+        lg1 = model.decode_logits(tok)
+        emb2 = torch.cat([emb, model.get_model().embed_tokens(tok)[:, None, :]], dim=1)
+        mask2 = torch.cat([mask, torch.ones_like(mask[:, :1])], dim=1)
+        ref = model.prefill_logits(emb2, mask2)
+        rel = rel_l2(lg1, ref)
+        record("c5.decode_vs_prefill", rel)
+        assert rel < 5e-3, rel
+        decisive = _margin(ref) > MARGIN_TAU
+        assert torch.equal(lg1.argmax(-1)[decisive], ref.argmax(-1)[decisive])
+        a = model.generate(ids, seqs, max_new_tokens=6, pad_token_id=0)
+        b = model.generate(ids, seqs, max_new_tokens=6, pad_token_id=0)
+        assert a.shape == (32, 6) and torch.equal(a, b)
+    finally:
+        del model
+        torch.cuda.empty_cache()

@@ -26,7 +26,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _cabi.lib()                          # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 2
+    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 3
     # pure host entry points that need no GPU
     cc = _cabi.CConfig.from_config(opa.llama3_8b())
     assert lib.opus_workspace_bytes(ctypes.byref(cc)) > 1 << 30
@@ -72,6 +72,24 @@ def test_alphabet_golden(gold, gold_dir):
     assert encode("L A<mask>G") == [4, 5, 32, 6]
     with pytest.raises(KeyError):
         encode("ACDj")
+
+
+def test_alphabet_literal_ids():
+    """Row E0 is UNPINNED by execution (fair_esm is absent, so the fixtures above were tokenised by this repo's own
+    batch_convert): these expectations are written out by hand from the published ESM-1b alphabet
+    (<cls> 0, <pad> 1, <eos> 2, <unk> 3, "LAGVSERTIDPKQNFYMHWCXBUZO.-" = 4..30, <null_1> 31, <mask> 32) and fair_esm's
+    documented BatchConverter behaviour (<cls> seq <eos>, right-padding with <pad>, whitespace dropped)."""
+    toks, lens = batch_convert(["MKTV"])
+    assert toks.tolist() == [[0, 20, 15, 11, 7, 2]] and lens.tolist() == [6]
+    toks, lens = batch_convert(["A<mask>G", "XBUZO", "K A\tE", ".-", "L"])
+    assert toks.tolist() == [[0, 5, 32, 6, 2, 1, 1], [0, 24, 25, 26, 27, 28, 2], [0, 15, 5, 9, 2, 1, 1],
+                             [0, 29, 30, 2, 1, 1, 1], [0, 4, 2, 1, 1, 1, 1]]
+    assert lens.tolist() == [5, 7, 5, 4, 3]
+    # the first residues of the sequence in fair_esm's README example
+    assert encode("MKTVRQERLKSIVRILERSKEPVSGAQLAEELSVSRQVIVQDIAYLRSLGYNIVATPRGYVLAGG")[:12] == [20, 15, 11, 7, 10, 16, 9, 10, 4, 15, 8, 12]
+    assert encode("<null_1><unk><pad>") == [31, 3, 1]
+    toks, lens = batch_convert(["", "AG"])                            # an empty string is <cls><eos>
+    assert toks.tolist() == [[0, 2, 1, 1], [0, 5, 6, 2]] and lens.tolist() == [2, 4]
 
 
 def test_synth_is_deterministic_and_fp16_exact():

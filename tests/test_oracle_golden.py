@@ -60,7 +60,24 @@ def test_projector_golden(gold, micro):
     np.testing.assert_allclose(z.numpy(), g["prot"], atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["one_each", "ragged_zero_two", "right_pad_labels", "no_mask", "single"])
+@pytest.mark.parametrize("tag,kw", [("linear", dict(switch_depth=1)), ("identity", dict(has_protein_projector=0)),
+                                    ("identity_linear", dict(has_protein_projector=0, switch_depth=1))])
+def test_projector_variants_golden(gold, tag, kw):
+    """'linear' switch projector (protein_mlp/builder.py:15-16) and the identity protein projector (opus_arch.py:70-80)."""
+    cfg = opa.micro(**kw)
+    W = {k: torch.from_numpy(v) for k, v in synth.canonical_weights(cfg, 0).items()}
+    g = gold("projector_variants")
+    x = torch.from_numpy(g[tag + ".pooled"])
+    y = oracle.protein_projector(x, W, cfg)
+    np.testing.assert_allclose(y.numpy(), g[tag + ".proj"], atol=1e-5, rtol=1e-5)
+    if not cfg.has_protein_projector:
+        assert torch.equal(y, x)
+    z = oracle.switch_projector(y, W, cfg)
+    np.testing.assert_allclose(z.numpy(), g[tag + ".prot"], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["one_each", "ragged_zero_two", "right_pad_labels", "no_mask", "single", "truncate_infer",
+                                 "truncate_train"])
 def test_splice_golden(gold, micro, tag):
     cfg, W = micro
     g = gold("splice")
@@ -70,9 +87,12 @@ def test_splice_golden(gold, micro, tag):
     labels = None
     if g[tag + ".labels"].size:
         labels = torch.where(ids == -200, torch.full_like(ids, -100), ids)
+    max_length = int(g[tag + ".max_length"]) if tag + ".max_length" in g.files else -1
     emb, m, pos, lab = oracle.splice_and_pad(ids, mask, prot, W["dec.embed_tokens"],
-                                             bool(g[tag + ".inference_mode"]), labels)
+                                             bool(g[tag + ".inference_mode"]), labels, max_length if max_length > 0 else None)
     assert np.array_equal(emb.numpy(), g[tag + ".embeds"])            # pure gather/copy: bit-exact
+    if max_length > 0:
+        assert emb.shape[1] == max_length                            # row S2 (opus_arch.py:234-237)
     if g[tag + ".mask_out"].size:
         assert np.array_equal(m.numpy(), g[tag + ".mask_out"].astype(bool))
     if g[tag + ".labels"].size:

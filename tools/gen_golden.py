@@ -215,7 +215,7 @@ def gold_splice(cfg, w, model):
     V = cfg.dec_vocab
     out = {}
 
-    def case(tag, rows, pad_id, inference_mode, with_labels=False, with_mask=True):
+    def case(tag, rows, pad_id, inference_mode, with_labels=False, with_mask=True, max_length=None):
         width = max(len(r) for r in rows)
         ids = torch.full((len(rows), width), pad_id, dtype=torch.long)
         for i, r in enumerate(rows):
@@ -232,11 +232,16 @@ def gold_splice(cfg, w, model):
         labels = None
         if with_labels:
             labels = torch.where(ids == -200, torch.full_like(ids, -100), ids)
+        if max_length is not None:                                  # row S2: opus_arch.py:234-237
+            model.config.tokenizer_model_max_length = max_length
         with torch.no_grad():
             res = model.prepare_inputs_labels_for_multimodal(
                 ids, None, mask if with_mask else None, None, labels, ["X"] * n_prot,
                 inference_mode=inference_mode)
             prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+        if max_length is not None:
+            del model.config.tokenizer_model_max_length
+        out[tag + ".max_length"] = np.array(-1 if max_length is None else max_length)
         _, pos, amask, _, emb, lab = res
         out[tag + ".ids"] = ids.numpy()
         out[tag + ".mask_in"] = mask.numpy()
@@ -255,6 +260,10 @@ def gold_splice(cfg, w, model):
     case("right_pad_labels", [[1] + r(5) + [-200] + r(3), [1] + r(2) + [-200] + r(6)], 2, False, with_labels=True)
     case("no_mask", [[1] + r(4) + [-200] + r(4), [1] + r(4) + [-200] + r(4)], 2, True, with_mask=False)
     case("single", [[1] + r(7) + [-200] + r(2)], 2, True)
+    # S2: config.tokenizer_model_max_length clips every spliced row (a cut through a protein block, a row shorter than
+    # the limit, a cut inside the text) - left-padded (inference) and right-padded with labels (training)
+    case("truncate_infer", [[1] + r(2) + [-200] + r(9), [1] + r(3), [1] + r(8) + [-200] + r(2)], 2, True, max_length=9)
+    case("truncate_train", [[1] + r(2) + [-200] + r(9), [1] + r(3) + [-200]], 2, False, with_labels=True, max_length=12)
     save("splice", **out)
 
 
@@ -265,6 +274,54 @@ def gold_projector(cfg, w, model):
         y = model.encode_projector_embedding(x)
         z = model.switch_projector_embedding(y)
     save("projector", pooled=x.numpy(), proj=y.numpy(), prot=z.numpy())
+
+
+def gold_projector_variants():
+    """Rows P2 'linear' (protein_mlp/builder.py:15-16) and the identity protein projector (opus_arch.py:70-80, selected by
+    pretrain_protein_projector_ckpt = None, which also makes the switch projector consume the raw encoder width,
+    protein_mlp/builder.py:14).  The identity module is the one the reference's own initialize_protein_modules installs."""
+    rng = np.random.default_rng(21)
+    out = {}
+    for tag, kw in (("linear", dict(switch_depth=1)), ("identity", dict(has_protein_projector=0)),
+                    ("identity_linear", dict(has_protein_projector=0, switch_depth=1))):
+        cfg = opa.micro(**kw)
+        w = synth.canonical_weights(cfg, seed=0)
+        if cfg.has_protein_projector:
+            model = build_ref_model(cfg, w, encoder=None)
+        else:
+            model = build_ref_model(opa.micro(switch_depth=cfg.switch_depth), synth.canonical_weights(opa.micro(switch_depth=cfg.switch_depth), seed=0), encoder=None)
+            inner = model.get_model()
+
+            class Enc:                                              # initialize_protein_modules calls load_model() on an existing encoder
+                def load_model(self):
+                    pass
+            inner.protein_encoder = Enc()
+            margs = types.SimpleNamespace(device="cpu", has_protein_encoder=True, has_switch_projector=True, esm_ckpt=None,
+                                          pretrain_protein_projector_ckpt=None, pretrain_switch_projector_ckpt=None,
+                                          hidden_size=cfg.dec_dim,
+                                          switch_projector_type="mlp%dx_gelu" % cfg.switch_depth if cfg.switch_depth > 1 else "linear")
+            inner.initialize_protein_modules(margs)                 # installs IdentityModule + a fresh switch projector
+            sw = inner.switch_projector
+            lin = [m for m in (sw if isinstance(sw, torch.nn.Sequential) else [sw]) if isinstance(m, torch.nn.Linear)]
+            assert lin[0].in_features == 1280                       # protein_mlp/builder.py:14 hard-codes the ESM2-650M width
+            first = torch.nn.Linear(cfg.switch_in, cfg.switch_out)  # the micro encoder is narrower
+            if isinstance(sw, torch.nn.Sequential):
+                sw[0] = first
+            else:
+                inner.switch_projector = sw = first
+            lin[0] = first
+            for i, m in enumerate(lin):
+                m.weight.data = tw(w, f"switch.{i}.weight")
+                m.bias.data = tw(w, f"switch.{i}.bias")
+        x = torch.from_numpy(rng.standard_normal((4, cfg.enc_dim)).astype(np.float32)) * 2.0
+        with torch.no_grad():
+            y = model.encode_projector_embedding(x)
+            z = model.switch_projector_embedding(y)
+        assert z.shape == (4, cfg.n_prot_tokens, cfg.dec_dim)
+        if not cfg.has_protein_projector:
+            assert y is x or torch.equal(y, x)
+        out[tag + ".pooled"], out[tag + ".proj"], out[tag + ".prot"] = x.numpy(), y.numpy(), z.numpy()
+    save("projector_variants", **out)
 
 
 def gold_esm(tag, cfg, w, seqs):
@@ -450,6 +507,7 @@ def main():
     hf = gold_esm("esm_micro", cfg, w, seqs)
     model = build_ref_model(cfg, w, FakeEncoder(hf))
     print("projector"); gold_projector(cfg, w, model)
+    print("projector variants"); gold_projector_variants()
     print("splice"); gold_splice(cfg, w, model)
     print("llama + generate (micro)"); gold_llama_and_generate(cfg, w, model, hf)
     for tag, fam in (("generate_micro_opt", opa.micro_opt()), ("generate_micro_qwen", opa.micro_qwen())):
