@@ -1,36 +1,38 @@
 #!/usr/bin/env python3
 """bench.py - proteins/s (+ generated tokens/s) of the multi_modality_v1 hot path on MI355X.
 
-One "step" = one pass of the whole path over one batch of synthetic input:
+One "step" = one pass of the whole path over one batch of synthetic input, inputs resident in HBM:
   ESM-2 encode -> modality projectors -> splice/left-pad -> Llama prefill -> N_new greedy decode steps
   (-> RCCL all-gather of the new ids when N > 1).
-Default workload (N = 1) = BASELINE.json configs[1]: OPUS-PLLM-Llama3-8B shape, batch 1, one
-512-residue protein, 89-id prompt with one <seq> (96 decoder positions), 32 new tokens, greedy, fp16.
-For N > 1 every rank runs the same per-GPU batch on its own proteins (weak scaling) with a full weight
-replica, exactly the reference's replica parallelism (eval/run_opus_ddp.py:77-79,138).
 
-Inputs are resident in HBM before the timed region (ESM token ids, prompt ids).  Prints ONE JSON line.
+Headline workload (`value`, every N): the per-GPU shard of BASELINE.json configs[3] - OPUS-PLLM-Llama3-8B shape, 64 proteins
+of 512 residues per GPU (batch 512 over 8 GPUs), 89-id prompt with one <seq> (96 decoder positions), 32 new tokens, greedy,
+fp16.  Every rank runs that shard on its own proteins with a full weight replica (weak scaling), exactly the reference's
+replica parallelism (eval/run_opus_ddp.py:77-79,138), so the N = 1 line is one shard and the 1 -> 8 curve is the configs[3]
+curve.  The latency configuration configs[1] (batch 1, one 512-residue protein; round 1's headline) is measured in the same
+process with the same rules and reported under "c2" in the same JSON line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(python -m torch.distributed.run, rendezvous on 127.0.0.1) before anything touches a GPU; under a launcher it reads
+RANK / LOCAL_RANK / WORLD_SIZE as usual.  Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL between the ranks of one node
 
-import torch                                                  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-import opus_pllm_amd as opa                                   # noqa: E402
-from opus_pllm_amd import synth                               # noqa: E402
-from opus_pllm_amd.alphabet import batch_convert              # noqa: E402
-
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense fp16 / bf16
+RDZV_TIMEOUT_S = 600       # every collective wait is bounded ("bound every RCCL wait with a timeout")
 _T0 = time.time()
 
 
@@ -52,61 +54,218 @@ def host_threads() -> int:
     return max(1, n)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--batch", type=int, default=1, help="proteins per GPU per step (C2: 1, C3/C4: 64)")
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=64, help="proteins per GPU per step (configs[3] shard / configs[2]: 64; configs[1]: 1)")
     p.add_argument("--residues", type=int, default=512)
-    p.add_argument("--mixed-lengths", action="store_true", help="C3: lengths uniform in [128,1024], seed 7")
+    p.add_argument("--mixed-lengths", action="store_true", help="configs[2]: lengths uniform in [128,1024], seed 7")
     p.add_argument("--new-tokens", type=int, default=32)
-    p.add_argument("--model", default="llama3_8b", choices=list(opa.PRESETS))
+    p.add_argument("--model", default="llama3_8b")
     p.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling head (reference default 0.1); 0 = greedy (BASELINE)")
     p.add_argument("--top-p", type=float, default=0.7)
     p.add_argument("--bucket", type=int, default=256, help="residues per length bucket with --mixed-lengths")
+    p.add_argument("--no-c2", action="store_true", help="skip the batch-1 latency configuration (configs[1])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
-def pmc_traffic():
-    """Average HBM bytes per gemm_skinny launch from the committed rocprofv3 PMC passes of this command
-    (tools/pmc_summary.py -> profiles/*_pmc_traffic.json; bench.py cannot run the profiler itself)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
-    rows = [v for k, v in d.items() if "gemm_skinny_kernel" in k]
-    n = sum(v["launches"] for v in rows)
-    return sum(v["fetch_bytes"] + v["write_bytes"] for v in rows) / n if n else None
+# ------------------------------------------------------------------------------------------------ self-launch
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def cpu_baseline(cfg, residues, n_text, n_new):
-    """The oracle (CPU fp32 port of the reference path) timed on this host's cores on a bounded sample:
-    one protein through the full-depth encoder + projectors + full-depth prefill + 4 decode steps,
-    extrapolated to n_new steps.  Decoder layers cycle through 4 distinct weight sets (3.5 GB fp32,
-    larger than the host caches) instead of materialising 32 GB; values are irrelevant to timing."""
+def self_launch(a) -> int:
+    """--gpus N > 1 without a launcher: start the N ranks as children of THIS process, which never touches a GPU
+    (no torch.cuda call has been made; exec'ing a GPU-initialised process is not allowed on this pool anyway)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"no WORLD_SIZE in the environment: launching {a.gpus} ranks: {' '.join(cmd[1:8])} ...")
+    return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """One batch of synthetic input resident in HBM + the step that runs the path over it."""
+
+    def __init__(self, model, cfg, a, rank, B, lengths, dev):
+        import torch
+        from opus_pllm_amd import synth
+        from opus_pllm_amd.alphabet import batch_convert
+        self.model, self.B, self.N_new, self.lengths = model, B, a.new_tokens, lengths
+        self.sampler = (a.temperature, a.top_p, 1234) if a.temperature > 0 else None
+        seqs = [synth.synth_protein(n, rank * B + i) for i, n in enumerate(lengths)]
+        self.bucket_rows = None
+        if len(set(lengths)) > 1:     # configs[2]: length buckets of --bucket residues (padding never exceeds one bucket)
+            order = sorted(range(B), key=lambda i: lengths[i])
+            groups = {}
+            for i in order:
+                groups.setdefault((lengths[i] + a.bucket - 1) // a.bucket, []).append(i)
+            self.d_tok, self.d_len, self.bucket_rows = [], [], []
+            for _, idxs in sorted(groups.items()):
+                t, l = batch_convert([seqs[i] for i in idxs])
+                self.d_tok.append(torch.from_numpy(t).to(dev)); self.d_len.append(torch.from_numpy(l).to(dev))
+                self.bucket_rows.append(torch.tensor(idxs, device=dev))
+        else:
+            toks, lens = batch_convert(seqs)
+            self.d_tok, self.d_len = torch.from_numpy(toks).to(dev), torch.from_numpy(lens).to(dev)
+        self.n_text = 89
+        self.ids = torch.tensor([synth.synth_prompt_ids(cfg.dec_vocab, rank * B + i, n_text=self.n_text) for i in range(B)], device=dev)
+        self.mask = torch.ones_like(self.ids, dtype=torch.bool)
+
+    def run(self):
+        """The path, no collective: [B, N_new] new ids on the device."""
+        return self.model.generate_from_tokens(self.d_tok, self.d_len, self.ids, self.mask, self.N_new, (), 0, self.bucket_rows,
+                                               sampler=self.sampler)
+
+
+class DryWorkload:
+    """OPUS_BENCH_DRYRUN=1 (tests/test_dist_cpu.py): no model and no GPU - exercises the launch, rendezvous, collective
+    ordering and JSON plumbing of this script on CPU ranks.  Its line is marked invalid."""
+
+    def __init__(self, B, n_new, rank):
+        import torch
+        self.B, self.N_new, self.lengths, self.n_text = B, n_new, [0] * B, 0
+        self.out = torch.arange(B * n_new, dtype=torch.long).view(B, n_new) + 1000 * rank
+
+    def run(self):
+        return self.out.clone()
+
+
+def timed(work, a, world, rank, dev, dist, cdev, steps, warmup):
+    """W untimed + exactly K timed steps between barrier + synchronize fences; max over ranks.  -> (seconds, last ids)"""
+    import torch
+    gathered = [torch.empty((work.B, work.N_new), dtype=torch.long, device=cdev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        out = work.run()
+        if world > 1:
+            dist.all_gather(gathered, out.contiguous().to(cdev))   # RCCL over xGMI: [B, N_new] ids per rank
+        return out
+
+    def fence():
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+
+    for i in range(warmup):
+        out = step()
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+        log(f"warmup step {i} done (batch {work.B})")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # the collective really spanned `world` ranks, in rank order, and carried this rank's ids
+        who = [torch.empty(1, dtype=torch.long, device=cdev) for _ in range(world)]
+        dist.all_gather(who, torch.tensor([rank], dtype=torch.long, device=cdev))
+        assert [int(w.item()) for w in who] == list(range(world)), who
+        assert len(gathered) == world and torch.equal(gathered[rank].cpu(), out.cpu())
+    assert out.shape == (work.B, work.N_new), out.shape
+    return dt, out
+
+
+# ------------------------------------------------------------------------------------------------ roofline
+HBM_CLASSES = ("gemm_skinny", "gemm_mid", "gemm_wide", "gemm_stream", "attn_decode", "splitk_reduce", "norm", "other", "decode_stack")
+
+
+def roofline(model, work, dev):
+    """One extra, untimed, eager pass of the same step with per-launch dispatch timestamps (hipExtLaunchKernelGGL start / stop
+    events on the launch stream; no collective in it, so every rank can run it).  The dominant kernel class is the one with
+    the largest summed duration; its roofline is HBM bytes for the weight-streaming / element-wise classes and MFMA FLOPs for
+    the tiled GEMM / prefill-attention classes.  Per-phase figures use the same algorithmic bytes / FLOPs over the summed
+    kernel time of the phase."""
+    import torch
+    classes, phases = model.timing_names()
+    model.timing(True)
+    work.run()
+    torch.cuda.synchronize(dev)
+    per = {}
+    for k in classes:
+        for ph in phases:
+            ms, n, by, fl = model.timing_get(k, ph)
+            if n:
+                per[(k, ph)] = (ms, n, by, fl)
+    model.timing(False)
+    tot = {}
+    for (k, ph), (ms, n, by, fl) in per.items():
+        t = tot.setdefault(k, [0.0, 0, 0.0, 0.0])
+        t[0] += ms; t[1] += n; t[2] += by; t[3] += fl
+    all_ms = sum(v[0] for v in tot.values())
+    dom = max(tot, key=lambda k: tot[k][0])
+
+    def block(ms, n, by, fl, hbm):
+        if hbm:
+            ach = by / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": by / n}
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                "algorithmic_flops_per_launch": fl / n}
+
+    ms, n, by, fl = tot[dom]
+    # a GEMM class is HBM-bound when it ran below the MFMA ridge (FLOP per byte << 400): decode, projector at small M
+    dom_hbm = dom in HBM_CLASSES or (by > 0 and fl / by < 200.0)
+    res = block(ms, n, by, fl, dom_hbm)
+    res.update({"kernel": f"{dom} (largest summed duration of the step: {100.0 * ms / all_ms:.0f} % of kernel time)",
+                "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "traffic": None,
+                "traffic_note": "HBM bytes from rocprofv3 PMC passes of this command are in profiles/ (r02_pmc_traffic.json); "
+                                "they are not collected inside bench.py",
+                "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])},
+                "launches": {k: v[1] for k, v in tot.items()}})
+    ph_out = {}
+    for ph in phases:
+        rows = [(k, v) for (k, p), v in per.items() if p == ph]
+        if not rows:
+            continue
+        pms = sum(v[0] for _, v in rows); pn = sum(v[1] for _, v in rows)
+        pby = sum(v[2] for _, v in rows); pfl = sum(v[3] for _, v in rows)
+        hbm = pby > 0 and pfl / max(pby, 1.0) < 200.0
+        b = block(pms, pn, pby, pfl, hbm)
+        ph_out[ph] = {"kernel_ms": pms, "launches": pn, "bound": b["bound"], "achieved": b["achieved"], "unit": b["unit"],
+                      "peak": b["peak"], "frac": b["frac"]}
+    res["phases"] = ph_out
+    return res
+
+
+def cpu_baseline(cfg, residues, n_text, n_new, batch):
+    """The oracle (CPU fp32 port of the reference path) timed on this host's cores on a bounded sample of the workload:
+    ONE protein of the batch through the full-depth encoder + projectors + full-depth prefill + 4 decode steps,
+    extrapolated to n_new steps (per-protein cost; the CPU has no batching gain to speak of at these sizes beyond weight
+    reuse, which the sample string states).  Decoder layers cycle through 4 distinct weight sets (3.5 GB fp32, larger than
+    the host caches) instead of materialising 32 GB; values are irrelevant to timing."""
+    import torch
     import oracle
     from oracle.llama import llama_forward
+    from opus_pllm_amd import synth
     nthreads = host_threads()
     torch.set_num_threads(nthreads)
     log(f"cpu_baseline: {nthreads} threads; generating fp32 weights")
     g = torch.Generator().manual_seed(0)
     W = {}
     distinct = 4
-
-    def mk(name, shape, std):
-        W[name] = torch.empty(shape).normal_(0.0, std, generator=g)
-
     for name, shape, std, mean in synth.canonical_spec(cfg):
         if name.startswith("dec.layers."):
             l = int(name.split(".")[2])
             if l >= distinct:
                 W[name] = W[name.replace(f"dec.layers.{l}.", f"dec.layers.{l % distinct}.")]
                 continue
-        mk(name, shape, std)
+        W[name] = torch.empty(shape).normal_(0.0, std, generator=g)
         if mean:
             W[name] += mean
     log("cpu_baseline: weights ready; timing the oracle")
@@ -134,140 +293,114 @@ def cpu_baseline(cfg, residues, n_text, n_new):
     enc, proj, pre, dec = t1 - t0, t2 - t1, t3 - t2, (t4 - t3) / steps
     total = enc + proj + pre + n_new * dec
     return {"value": 1.0 / total, "unit": "proteins/s", "cores": nthreads, "kind": "port",
-            "sample": f"1 protein ({residues} residues) full-depth: encode {enc:.2f}s + projectors {proj:.2f}s + "
-                      f"prefill(T={emb.shape[1]}) {pre:.2f}s + {steps} decode steps ({dec:.3f}s each) "
-                      f"extrapolated to {n_new}; PyTorch CPU fp32, {nthreads} threads",
+            "sample": f"1 of the {batch} proteins of a step ({residues} residues) at full depth, batch 1: encode {enc:.2f}s + "
+                      f"projectors {proj:.2f}s + prefill(T={emb.shape[1]}) {pre:.2f}s + {steps} decode steps ({dec:.3f}s each) "
+                      f"extrapolated to {n_new}; PyTorch CPU fp32, {nthreads} threads; proteins/s = 1 / that time",
             "generated_tokens_per_sec": n_new / total}
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    # one rank per GPU; OPUS_BENCH_BACKEND=gloo (+ ranks sharing a GPU) exists only to rehearse the N > 1 code
-    # path on a one-GPU box - the driver's multi-GPU runs use nccl (= RCCL over xGMI)
+    world = int(env_world or "1")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or drop WORLD_SIZE and "
+                         f"let bench.py start the ranks itself)")
+    dry = os.environ.get("OPUS_BENCH_DRYRUN") == "1"
+
+    import torch
+    sys.path.insert(0, ROOT)
+    # one rank per GPU; OPUS_BENCH_BACKEND=gloo (+ ranks sharing a GPU) exists only to rehearse the N > 1 code path on a
+    # one-GPU box or on CPU - the driver's multi-GPU runs use nccl (= RCCL over xGMI)
     backend = os.environ.get("OPUS_BENCH_BACKEND", "nccl")
-    local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = None
+    if not dry:
+        local = local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=RDZV_TIMEOUT_S)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collectives run
-
-    from opus_pllm_amd.model import OpusLlamaForCausalLM
-    from opus_pllm_amd.weights import DeviceWeights
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"{dist.get_world_size()} ranks joined, --gpus {a.gpus} asked")
+    cdev = dev if (backend == "nccl" and not dry) else torch.device("cpu")     # where collectives run
 
     B, N_new = a.batch, a.new_tokens
-    lengths = synth.synth_lengths(B * world)[rank * B:(rank + 1) * B] if a.mixed_lengths else [a.residues] * B
-    n_text = 89
-    cfg = opa.PRESETS[a.model](max_batch=B, max_enc_tokens=max(lengths) + 2, max_prompt=n_text + 7,
-                               max_new_tokens=N_new)
-    log(f"building {a.model}: {synth.param_count(cfg) / 1e9:.2f} B synthetic parameters on {dev}")
-    weights = DeviceWeights.synthetic(cfg, 0, dev)
-    model = OpusLlamaForCausalLM(cfg, weights, dev)
-    torch.cuda.synchronize(dev)
-    log(f"weights {weights.nbytes() / 1e9:.1f} GB resident")
-    seqs = [synth.synth_protein(n, rank * B + i) for i, n in enumerate(lengths)]
-    bucket_rows = None
-    if a.mixed_lengths:     # C3: length buckets of --bucket residues (padding never exceeds one bucket), resident in HBM
-        order = sorted(range(B), key=lambda i: lengths[i])
-        groups = {}
-        for i in order:
-            groups.setdefault((lengths[i] + a.bucket - 1) // a.bucket, []).append(i)
-        d_tok, d_len, bucket_rows = [], [], []
-        for _, idxs in sorted(groups.items()):
-            t, l = batch_convert([seqs[i] for i in idxs])
-            d_tok.append(torch.from_numpy(t).to(dev)); d_len.append(torch.from_numpy(l).to(dev))
-            bucket_rows.append(torch.tensor(idxs, device=dev))
+    if dry:
+        main_work = DryWorkload(B, N_new, rank)
+        c2_work = None if a.no_c2 or B == 1 else DryWorkload(1, N_new, rank)
+        cfg = model = None
     else:
-        toks, lens = batch_convert(seqs)
-        d_tok = torch.from_numpy(toks).to(dev)
-        d_len = torch.from_numpy(lens).to(dev)
-    ids = torch.tensor([synth.synth_prompt_ids(cfg.dec_vocab, rank * B + i, n_text=n_text) for i in range(B)], device=dev)
-    mask = torch.ones_like(ids, dtype=torch.bool)
-    gathered = [torch.empty((B, N_new), dtype=torch.long, device=cdev) for _ in range(world)] if world > 1 else None
-
-    def step():
-        out = model.generate_from_tokens(d_tok, d_len, ids, mask, N_new, (), 0, bucket_rows,
-                                         sampler=(a.temperature, a.top_p, 1234) if a.temperature > 0 else None)
-        if world > 1:
-            dist.all_gather(gathered, out.contiguous().to(cdev))   # RCCL over xGMI: [B, N_new] ids per rank
-        return out
-
-    def fence():
+        import opus_pllm_amd as opa
+        from opus_pllm_amd import synth
+        from opus_pllm_amd.model import OpusLlamaForCausalLM
+        from opus_pllm_amd.weights import DeviceWeights
+        lengths = synth.synth_lengths(B * world)[rank * B:(rank + 1) * B] if a.mixed_lengths else [a.residues] * B
+        cfg = opa.PRESETS[a.model](max_batch=B, max_enc_tokens=max(max(lengths), a.residues) + 2, max_prompt=96, max_new_tokens=N_new)
+        log(f"building {a.model}: {synth.param_count(cfg) / 1e9:.2f} B synthetic parameters on {dev}")
+        weights = DeviceWeights.synthetic(cfg, 0, dev)
+        model = OpusLlamaForCausalLM(cfg, weights, dev)
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        log(f"weights {weights.nbytes() / 1e9:.1f} GB resident")
+        main_work = Workload(model, cfg, a, rank, B, lengths, dev)
+        c2_work = None if a.no_c2 or B == 1 else Workload(model, cfg, a, rank, 1, [a.residues], dev)
 
-    for i in range(a.warmup):
-        out = step()
-        torch.cuda.synchronize(dev)
-        log(f"warmup step {i} done")
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert out.shape == (B, N_new)
-    log(f"timed {a.steps} steps: {1e3 * dt / a.steps:.2f} ms/step")
-
+    dt, _ = timed(main_work, a, world, rank, dev, dist, cdev, a.steps, a.warmup)
+    log(f"timed {a.steps} steps at batch {B}: {1e3 * dt / a.steps:.2f} ms/step")
+    mixed = a.mixed_lengths
     res = {
         "metric": "proteins_per_sec", "value": world * B * a.steps / dt, "unit": "proteins/s",
         "generated_tokens_per_sec": world * B * N_new * a.steps / dt,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"OPUS-PLLM-{a.model} shape: batch {B}/GPU, "
-                               f"{'mixed 128-1024' if a.mixed_lengths else a.residues}-residue proteins, "
-                               f"{n_text}-id prompt (+8 protein tokens = 96 positions), {N_new} new tokens, greedy "
-                               f"(BASELINE configs[1])" if B == 1 and not a.mixed_lengths else
-                               f"OPUS-PLLM-{a.model} shape: batch {B}/GPU, "
-                               f"{'mixed 128-1024' if a.mixed_lengths else a.residues}-residue proteins, "
-                               f"{n_text}-id prompt, {N_new} new tokens, greedy",
-                   "batch_per_gpu": B, "residues": a.residues, "new_tokens": N_new,
+                               f"{'mixed 128-1024' if mixed else a.residues}-residue proteins, 89-id prompt (+8 protein tokens = 96 "
+                               f"positions), {N_new} new tokens, greedy"
+                               + (" (BASELINE configs[3] per-GPU shard: batch 512 over 8 GPUs)" if B == 64 and not mixed and a.residues == 512 else "")
+                               + (" (BASELINE configs[2])" if B == 64 and mixed else "")
+                               + (" (BASELINE configs[1])" if B == 1 and not mixed and a.residues == 512 else ""),
+                   "batch_per_gpu": B, "residues": "128-1024" if mixed else a.residues, "new_tokens": N_new,
                    "parallelism": f"replicas x{world} (batch-sharded), all-gather of ids"},
     }
+    if dry:
+        res["data"] = "DRY RUN - no model, no GPU work: launch / collective plumbing only"
+        res["invalid"] = True
 
-    if rank == 0 and not a.no_roofline:
-        # dominant kernel = the weight-streaming skinny GEMM (decode + projector + B=1 prefill): timed
-        # per launch with hipEvents on the launch stream in an extra, untimed pass of the same step.
-        model.timing(True)
-        step()
-        torch.cuda.synchronize(dev)
-        # skinny launches carry their own dispatch start/end timestamps (hipExtLaunchKernelGGL events in the
-        # library's timing mode) - the same interval rocprofv3 --kernel-trace reports per dispatch
-        ms, n, by = model.timing_get("skinny_gemm")
-        parts = {k: model.timing_get(k) for k in ("tile_gemm", "attn_prefill", "attn_decode", "other")}
-        model.timing(False)
-        ach = by / (ms * 1e-3) / 1e9 if ms > 0 else None           # no skinny launch at this batch size
-        res["roofline"] = {"bound": "hbm", "kernel": "gemm_skinny_kernel (weight-streaming GEMM, M<=16)",
-                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": pmc_traffic() if ach else None,
-                           "algorithmic_bytes_per_launch": by / max(n, 1),
-                           "launches_per_step": n, "avg_launch_us": 1e3 * ms / max(n, 1),
-                           "algorithmic_bytes_per_step": by,
-                           "event_ms_per_step": {"skinny_gemm": ms, **{k: v[0] for k, v in parts.items()}}}
+    if c2_work is not None:      # configs[1]: batch 1, same rules (every rank runs it so that collectives stay matched)
+        dt2, _ = timed(c2_work, a, world, rank, dev, dist, cdev, a.steps, a.warmup)
+        log(f"timed {a.steps} steps at batch 1: {1e3 * dt2 / a.steps:.2f} ms/step")
+        res["c2"] = {"workload": f"OPUS-PLLM-{a.model} shape: batch 1/GPU, {a.residues}-residue protein, 96 positions, {N_new} new "
+                                 f"tokens, greedy (BASELINE configs[1])",
+                     "value": world * a.steps / dt2, "unit": "proteins/s", "generated_tokens_per_sec": world * N_new * a.steps / dt2,
+                     "ms_per_step": 1e3 * dt2 / a.steps, "steps": a.steps, "warmup": a.warmup}
+
+    if not dry and not a.no_roofline:
+        # every rank runs the (collective-free) measurement pass, rank 0 reports it
+        r_main = roofline(model, main_work, dev)
+        r_c2 = roofline(model, c2_work, dev) if c2_work is not None else None
+        if rank == 0:
+            res["roofline"] = r_main
+            if r_c2 is not None:
+                res["c2"]["roofline"] = r_c2
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(cfg, lengths[0], n_text, N_new)
+    if rank == 0 and world == 1 and not dry and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, main_work.lengths[0], main_work.n_text, N_new, B)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -262,6 +262,9 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
     rank = accelerator.process_index if accelerator is not None else int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device(kwargs.pop("device", f"cuda:{rank}"))
     cap = {k: kwargs.pop(k) for k in ("max_batch", "max_enc_tokens", "max_prompt", "max_new_tokens") if k in kwargs}
+    # capacity_from(tokenizer, cfg) -> dict of capacity fields computed once the tokenizer exists (eval_ddp.py sizes
+    # max_prompt from the tokenised dataset instead of a fixed cap)
+    capacity_from = kwargs.pop("capacity_from", None)
     depth = switch_depth_from_type(switch_projector_type)
     if not (model_name is not None and model_base_path):
         raise NotImplementedError
@@ -271,8 +274,10 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
     has_proj = 0 if cstp_path is None else 1
     if str(model_base_path).startswith("synthetic:"):
         cfg = PRESETS[model_base_path.split(":", 1)[1]](switch_depth=depth, has_protein_projector=has_proj, **cap)
-        weights = DeviceWeights.synthetic(cfg, int(kwargs.pop("seed", 0)), device)
         tokenizer = SyntheticTokenizer(cfg.dec_vocab)
+        if capacity_from is not None:
+            cfg = cfg.with_capacity(**capacity_from(tokenizer, cfg)).validate()
+        weights = DeviceWeights.synthetic(cfg, int(kwargs.pop("seed", 0)), device)
         model = OpusLlamaForCausalLM(cfg, weights, device, eos_token_id=tokenizer.eos_token_id,
                                      pad_token_id=tokenizer.pad_token_id)
         return tokenizer, model, 512
@@ -302,6 +307,8 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
         if family == "llama":
             tokenizer.pad_token = tokenizer.unk_token = tokenizer.eos_token
             tokenizer.pad_token_id = tokenizer.unk_token_id = tokenizer.eos_token_id
+    if capacity_from is not None:
+        cfg = cfg.with_capacity(**capacity_from(tokenizer, cfg)).validate()
     if accelerator is not None:
         accelerator.wait_for_everyone()
     lora = None

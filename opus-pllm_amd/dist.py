@@ -49,6 +49,36 @@ def all_gather_ids(local: torch.Tensor, pad_id: int = 0, group=None) -> torch.Te
     return torch.cat([o[:b] for o, (b, _) in zip(out, shapes)], dim=0)
 
 
+def all_gather_logits(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Optional parity dump (north_star "all-gather of logits"): fp32 [B_local, V] last-step logits of every
+    rank -> [sum B_local, V] in rank order.  32.8 MB per rank at 64 x 128 256 - one all-gather over xGMI; B_local may differ
+    per rank (the first n % world ranks hold one more row), so the rows are padded to the largest shard and trimmed."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    nrow = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    rows = [torch.empty_like(nrow) for _ in range(world)]
+    dist.all_gather(rows, nrow, group=group)
+    rows = [int(r.item()) for r in rows]
+    buf = torch.zeros((max(rows), local.shape[1]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return torch.cat([o[:n] for o, n in zip(out, rows)], dim=0)
+
+
+def init_process_group(backend: str, rank: int, world: int, device=None, timeout_s: int = 600) -> None:
+    """torch.distributed.init_process_group with a FINITE timeout on every collective wait (the reference's accelerate
+    launcher leaves NCCL's default; a stuck rank would otherwise hold all 8 GPUs of the node)."""
+    import datetime
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+
+
 def gather_object(obj: list, group=None) -> list:
     """accelerate.utils.gather_object for a list per rank (run_opus_ddp.py:138): concatenation in rank order."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

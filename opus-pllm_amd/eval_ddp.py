@@ -7,7 +7,8 @@
 
 Flow (run_opus_ddp.py:47-148): load -> read JSON -> contiguous split over ranks -> batches of 8 -> prompt ->
 tokenizer_seq_token -> left-pad -> generate -> decode, cut at '###' -> gather in rank order -> rank 0 saves.
-`--use_input_embed` consumes the `.jsonl` written by `generate_esm_embedding.py`.
+`--use_input_embed` consumes the `.jsonl` written by `generate_esm_embedding.py`: the shard's embeddings go
+through the modality projectors ONCE at M = shard size (>= 512: MFMA-bound GEMMs), decode batches consume the protein tokens.
 Differences, all deliberate: the gather moves token ids
 (int tensor all-gather over RCCL) instead of pickled strings, task metrics (metrics_computing_opi.py) are not run.
 """
@@ -28,21 +29,51 @@ from opus_pllm_amd.builder import load_pretrained_model, return_cstp_path      #
 from opus_pllm_amd.prompt import after_process_output, build_prompt, max_new_tokens_for   # noqa: E402
 
 
+def annotate(model, tokenizer, items, input_path, batch_size, max_new, temperature=0.0, top_p=0.7, num_beams=1,
+             use_input_embed=False, device=None):
+    """The batch loop of run_opus_ddp.py:88-134 over this rank's items -> [n, max_new] new ids (rows padded with eos).
+
+    use_input_embed (two-stage pipeline): the `input_embed` vectors of the WHOLE shard go through the modality
+    projectors once, at M = len(items) (model.project_dataset), and the decode batches consume the stored protein tokens;
+    without it every batch encodes and projects its own proteins, as the reference does."""
+    dev = device or model.device
+    outs = []
+    prot_all = None
+    if use_input_embed and items:
+        prot_all = model.project_dataset(torch.tensor([q["input_embed"] for q in items], dtype=torch.float32, device=dev))
+    for i in range(0, len(items), batch_size):
+        batch = items[i:i + batch_size]
+        prompts = [build_prompt(q["instruction"], input_path) for q in batch]
+        ids = [opa.tokenizer_seq_token(p, tokenizer, opa.DEFAULT_SEQ_TOKEN_INDEX, return_tensors="pt").to(dev) for p in prompts]
+        ids = opa.left_pad_sequence(ids, padding_value=tokenizer.pad_token_id, batch_first=True)
+        mask = ids != tokenizer.pad_token_id
+        extra = {} if prot_all is None else {"protein_tokens": prot_all[i:i + len(batch)]}
+        with torch.inference_mode():
+            out = model.generate(ids, [q["input"] for q in batch], attention_mask=mask, pad_token_id=tokenizer.eos_token_id,
+                                 do_sample=temperature > 0, temperature=temperature, top_p=top_p,
+                                 num_beams=num_beams, max_new_tokens=max_new, use_cache=True, **extra)
+        full = torch.full((out.shape[0], max_new), tokenizer.eos_token_id, dtype=torch.long, device=dev)
+        full[:, : out.shape[1]] = out
+        outs.append(full)
+    return torch.cat(outs) if outs else torch.empty((0, max_new), dtype=torch.long, device=dev)
+
+
+def prompt_capacity(tokenizer, items, input_path, n_prot_tokens) -> int:
+    """Decoder positions the longest prompt of the shard needs after the splice (each <seq> becomes n_prot_tokens)."""
+    need = 1
+    for q in items:
+        ids = opa.tokenizer_seq_token(build_prompt(q["instruction"], input_path), tokenizer, opa.DEFAULT_SEQ_TOKEN_INDEX)
+        need = max(need, len(ids) + (n_prot_tokens - 1) * sum(1 for t in ids if t == opa.DEFAULT_SEQ_TOKEN_INDEX))
+    return need
+
+
 def eval_model(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    model_name = opa.get_model_name_from_path(args.model_base_path)
-    cstp_path = return_cstp_path(args.opus_pllm_weights_path, "modality_encoder/modality_encoding_adapter.ckpt")
-    tokenizer, model, _ = load_pretrained_model(args.model_base_path, args.opus_pllm_weights_path, model_name,
-                                                args.load_8bit, args.load_4bit, switch_projector_type=args.switch_projector_type,
-                                                cstp_path=cstp_path, device=f"cuda:{local}", max_batch=args.batch_size,
-                                                max_enc_tokens=args.max_residues + 2, max_prompt=args.max_prompt,
-                                                max_new_tokens=256)
+        odist.init_process_group("nccl", rank, world, torch.device("cuda", local), timeout_s=args.collective_timeout)
     if args.input_path.endswith(".jsonl"):            # stage-2 input: one item per line (generate_esm_embedding.py)
         qs = [json.loads(line) for line in open(args.input_path) if line.strip()]
     else:
@@ -52,26 +83,19 @@ def eval_model(args):
     lo, hi = odist.shard_bounds(n, rank, world)
     mine = qs[lo:hi]
     max_new = max_new_tokens_for(args.input_path) if args.max_new_tokens is None else args.max_new_tokens
+    model_name = opa.get_model_name_from_path(args.model_base_path)
+    cstp_path = return_cstp_path(args.opus_pllm_weights_path, "modality_encoder/modality_encoding_adapter.ckpt")
+    # capacity of the context: the reference has no cap; here the KV cache is sized once, from what this run will really ask for
+    tokenizer, model, _ = load_pretrained_model(args.model_base_path, args.opus_pllm_weights_path, model_name,
+                                                args.load_8bit, args.load_4bit, switch_projector_type=args.switch_projector_type,
+                                                cstp_path=cstp_path, device=f"cuda:{local}", max_batch=args.batch_size,
+                                                max_enc_tokens=args.max_residues + 2, max_prompt=8, max_new_tokens=max_new,
+                                                capacity_from=lambda tok, cfg: dict(
+                                                    max_prompt=max(args.max_prompt or 0, prompt_capacity(tok, mine, args.input_path, cfg.n_prot_tokens))))
     dev = torch.device("cuda", local)
-    outs = []
     t0 = time.time()
-    for i in range(0, len(mine), args.batch_size):
-        batch = mine[i:i + args.batch_size]
-        prompts = [build_prompt(q["instruction"], args.input_path) for q in batch]
-        ids = [opa.tokenizer_seq_token(p, tokenizer, opa.DEFAULT_SEQ_TOKEN_INDEX, return_tensors="pt").to(dev) for p in prompts]
-        ids = opa.left_pad_sequence(ids, padding_value=tokenizer.pad_token_id, batch_first=True)
-        mask = ids != tokenizer.pad_token_id
-        seq_embedding = None
-        if args.use_input_embed:      # two-stage pipeline: precomputed ESM-2 embeddings (opus_arch.py:151-161)
-            seq_embedding = torch.tensor([q["input_embed"] for q in batch], dtype=torch.float32, device=dev)
-        with torch.inference_mode():
-            out = model.generate(ids, [q["input"] for q in batch], attention_mask=mask, pad_token_id=tokenizer.eos_token_id,
-                                 seq_embedding=seq_embedding, do_sample=args.temperature > 0, temperature=args.temperature, top_p=args.top_p,
-                                 num_beams=args.num_beams, max_new_tokens=max_new, use_cache=True)
-        full = torch.full((out.shape[0], max_new), tokenizer.eos_token_id, dtype=torch.long, device=dev)
-        full[:, : out.shape[1]] = out
-        outs.append(full)
-    local_ids = torch.cat(outs) if outs else torch.empty((0, max_new), dtype=torch.long, device=dev)
+    local_ids = annotate(model, tokenizer, mine, args.input_path, args.batch_size, max_new, args.temperature, args.top_p,
+                         args.num_beams, args.use_input_embed, dev)
     all_ids = odist.all_gather_ids(local_ids, tokenizer.eos_token_id)
     if rank == 0:
         dt = time.time() - t0
@@ -99,7 +123,8 @@ if __name__ == "__main__":
     p.add_argument("--load-8bit", action="store_true")
     p.add_argument("--batch_size", type=int, default=8)          # hard-coded 8 in the reference (:75)
     p.add_argument("--max_residues", type=int, default=1024)
-    p.add_argument("--max_prompt", type=int, default=256)
+    p.add_argument("--max_prompt", type=int, default=None, help="decoder positions to reserve (default: what the longest prompt needs)")
+    p.add_argument("--collective_timeout", type=int, default=1800, help="seconds before a stuck RCCL wait aborts the run")
     p.add_argument("--use_input_embed", action="store_true",
                    help="stage 2 of the two-stage pipeline: take `input_embed` from the .jsonl instead of running ESM-2")
     eval_model(p.parse_args())

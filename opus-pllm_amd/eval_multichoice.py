@@ -47,7 +47,7 @@ def eval_model(args):
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        odist.init_process_group("nccl", rank, world, torch.device("cuda", local), timeout_s=1800)
     model_name = opa.get_model_name_from_path(args.model_base_path)
     cstp_path = return_cstp_path(args.opus_pllm_weights_path, "modality_encoder/modality_encoding_adapter.ckpt")
     tokenizer, model, _ = load_pretrained_model(args.model_base_path, args.opus_pllm_weights_path, model_name,

@@ -198,17 +198,36 @@ class OpusLlamaForCausalLM:
         self._leave()
         return emb, mo, po
 
+    def project_dataset(self, pooled: torch.Tensor) -> torch.Tensor:
+        """The batched projector stage of the two-stage pipeline: pooled ESM-2 embeddings of a whole dataset
+        shard fp32 [N, enc_dim] (the `input_embed` field written by generate_esm_embedding.py, consumed by the reference at
+        opus_arch.py:151-161) -> protein tokens fp16 [N, n_prot_tokens, hidden] in ONE call, i.e. the modality projectors run
+        at M = N (>= 512 for any real dataset: MFMA-bound GEMMs, processed in chunks of max(max_batch, 1024) rows) instead of
+        re-streaming their 2.5 GB of weights for every batch of 8.  Feed slices of the result to generate(protein_tokens=...)."""
+        x = pooled.to(self.device, torch.float32).contiguous()
+        N = x.shape[0]
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            z = torch.empty((N, self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16, device=self.device)
+            _cabi.check(self._lib.opus_projector_forward(self._ctx, x.data_ptr(), N, z.data_ptr(), None, s))
+        self._leave()
+        return z
+
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
-                                             seq, seq_embedding=None, inference_mode=False):
+                                             seq, seq_embedding=None, inference_mode=False, protein_tokens=None):
         """opus_arch.py:133-294.  Returns (None, position_ids|None, attention_mask|None, past_key_values,
-        inputs_embeds [B,T,H] fp16, labels|None); inputs unchanged when seq is None or T == 1."""
+        inputs_embeds [B,T,H] fp16, labels|None); inputs unchanged when seq is None or T == 1.
+        protein_tokens (an extension, see project_dataset): already projected [n, n_prot_tokens, hidden] blocks."""
         if seq is None or self.get_protein_encoder() is None or input_ids.shape[1] == 1:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels
-        if seq_embedding is None:
-            seq_embedding = self.encode_seq2embedding(seq)
-        seq_embedding = self.encode_projector_embedding(seq_embedding)
-        if self.config.has_switch_projector:
-            seq_embedding = self.switch_projector_embedding(seq_embedding)
+        if protein_tokens is not None:
+            seq_embedding = protein_tokens
+        else:
+            if seq_embedding is None:
+                seq_embedding = self.encode_seq2embedding(seq)
+            seq_embedding = self.encode_projector_embedding(seq_embedding)
+            if self.config.has_switch_projector:
+                seq_embedding = self.switch_projector_embedding(seq_embedding)
         if seq_embedding.ndimension() == 2:
             seq_embedding = seq_embedding.unsqueeze(1)
         elif seq_embedding.ndimension() != 3:
@@ -227,6 +246,7 @@ class OpusLlamaForCausalLM:
     def generate(self, inputs: Optional[torch.Tensor] = None, seq=None, seq_embedding=None, **kwargs) -> torch.LongTensor:
         """opus_llama.py:95-132 + GenerationMixin greedy search: returns ONLY the new ids [B, n_new]."""
         kwargs.pop("position_ids", None)
+        protein_tokens = kwargs.pop("protein_tokens", None)
         attention_mask = kwargs.pop("attention_mask", None)
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")
@@ -257,7 +277,7 @@ class OpusLlamaForCausalLM:
         if seq is not None:
             _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(
                 inputs, None, attention_mask if attention_mask is not None else torch.ones_like(inputs, dtype=torch.bool),
-                None, None, seq, seq_embedding, inference_mode=True)
+                None, None, seq, seq_embedding, inference_mode=True, protein_tokens=protein_tokens)
         else:
             dummy = torch.zeros((inputs.shape[0], self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16,
                                 device=self.device)

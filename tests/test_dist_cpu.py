@@ -29,7 +29,7 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    odist.init_process_group("gloo", rank, world, timeout_s=120)
     try:
         n = 7                                         # 7 inputs over 2 ranks -> 4 + 3
         lo, hi = odist.shard_bounds(n, rank, world)
@@ -37,7 +37,8 @@ def _worker(rank, world, port, q):
         local = torch.arange(lo, hi)[:, None] * 100 + torch.arange(n_new)[None, :]
         allg = odist.all_gather_ids(local, pad_id=-1)
         objs = odist.gather_object([f"r{rank}-{i}" for i in range(lo, hi)])
-        q.put((rank, allg.tolist(), objs))
+        logits = odist.all_gather_logits(torch.arange(lo, hi, dtype=torch.float32)[:, None] + torch.arange(6)[None, :] / 8)
+        q.put((rank, allg.tolist(), objs, logits.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -54,11 +55,49 @@ def test_all_gather_ids_and_objects_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     expect = [[i * 100 + j if j < (5 if i < 4 else 3) else -1 for j in range(5)] for i in range(7)]
-    for rank, allg, objs in res:
+    for rank, allg, objs, logits in res:
         assert allg == expect                            # same on every rank, rows in input order
         assert objs == [f"r{0 if i < 4 else 1}-{i}" for i in range(7)]
+        assert logits == [[i + j / 8 for j in range(6)] for i in range(7)]      # uneven shards (4 + 3 rows), rank order
 
 
 def test_single_process_passthrough():
     t = torch.arange(6).view(2, 3)
     assert odist.all_gather_ids(t) is t and odist.gather_object([1, 2]) == [1, 2]
+
+
+# ------------------------------------------------------------------------------------------------ bench.py launch plumbing
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher: the parent starts 2 ranks (torch.distributed.run on 127.0.0.1), they
+    rendezvous (gloo here), run the same sequence of collectives - the timed loops of both workloads, the max-reduce, the rank
+    census - and rank 0 prints ONE line with n_gpus = 2.  OPUS_BENCH_DRYRUN replaces the model by a stub (no GPU in this
+    container): what is covered is the launch / collective plumbing that deadlocked in round 1's review."""
+    import json
+    r = _run_bench(["--gpus", "2", "--batch", "3", "--steps", "2", "--warmup", "1", "--new-tokens", "4"],
+                   {"OPUS_BENCH_DRYRUN": "1", "OPUS_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["invalid"] is True
+    assert d["config"]["batch_per_gpu"] == 3 and d["scaling"] == "weak" and "c2" in d
+    assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _run_bench(["--gpus", "2"], {"OPUS_BENCH_DRYRUN": "1", "WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    r = _run_bench(["--gpus", "1"], {"OPUS_BENCH_DRYRUN": "1", "WORLD_SIZE": "2", "RANK": "0", "OPUS_BENCH_BACKEND": "gloo"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

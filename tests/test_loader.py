@@ -230,6 +230,58 @@ def test_two_stage_pipeline_matches_one_stage(tmp_path):
     assert torch.equal(a, b)
 
 
+@pytest.mark.gpu
+def test_two_stage_eval_loop_projects_the_shard_once(tmp_path):
+    """eval_ddp.annotate: --use_input_embed projects the whole shard in ONE projector call (M = shard size, beyond
+    max_batch) and the decode batches consume the stored protein tokens: same ids as the one-stage loop, and the timing
+    records show a single projector pass (3 GEMM launches: proj, switch.0, switch.1) instead of one per batch."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(here, "opus-pllm_amd", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    gen, ddp = load("generate_esm_embedding"), load("eval_ddp")
+    tok, model, _ = builder.load_pretrained_model("synthetic:c1_tiny", "synthetic", "c1_tiny", device="cuda:0", max_batch=4,
+                                                  max_enc_tokens=258, max_prompt=64, max_new_tokens=8)
+    items = [dict(instruction=f"What is the function of protein {i}?", input=synth.synth_protein(20 + 11 * (i % 9), i), output="x")
+             for i in range(11)]
+    staged = gen.embed_dataset(model, items, None, batch_size=4)
+    one = ddp.annotate(model, tok, items, "", 4, 8, use_input_embed=False)
+    model.timing(True)
+    two = ddp.annotate(model, tok, staged, "", 4, 8, use_input_embed=True)
+    n_proj = sum(model.timing_get(k, "project")[1] for k in model.timing_names()[0] if k.startswith("gemm_"))
+    n_enc = model.timing_get("*", "encode")[1]
+    model.timing(False)
+    assert one.shape == (11, 8) and torch.equal(one, two)
+    assert n_proj == 3 and n_enc == 0, (n_proj, n_enc)
+    assert ddp.prompt_capacity(tok, items, "", model.cfg.n_prot_tokens) <= 64
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_on_one_gpu_with_gloo():
+    """`python bench.py --gpus 2` with no launcher and OPUS_BENCH_BACKEND=gloo on a one-GPU box: two ranks share the card,
+    run the real path (C1-size model), gather their ids, and rank 0 prints one line with n_gpus = 2, a roofline block and the
+    batch-1 sub-run.  (Round 1's script ran a single rank here and would have deadlocked under a real launcher.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OPUS_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(here, "bench.py"), "--gpus", "2", "--model", "c1_tiny", "--batch", "4",
+                        "--residues", "96", "--new-tokens", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["batch_per_gpu"] == 4 and "invalid" not in d
+    assert d["value"] > 0 and d["c2"]["value"] > 0
+    assert d["roofline"]["frac"] > 0 and set(d["roofline"]["phases"]) >= {"encode", "project", "prefill", "decode"}
+
+
 def test_opt_and_qwen_state_dict_mappings_roundtrip():
     """canonical_from_hf_opt / canonical_from_hf_llama (Qwen2 biases) invert the naming of the transformers state dicts;
     absent OPT biases / LayerNorm parameters become zeros / ones, an absent lm_head is the tied embedding."""
