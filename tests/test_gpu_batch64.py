@@ -25,8 +25,12 @@ from gpu_helpers import LazyCanon, record, rel_l2
 pytestmark = pytest.mark.gpu
 
 MARGIN_TAU = 0.05          # oracle / reference top-1 margin above which a greedy id must match exactly
-ROW_VS_BATCH = 2e-3        # same math on different kernels (batch-1 skinny path vs batch-64 tile / wide / ring path)
-REL_L2 = 1.5e-2            # fp16-operand HIP path vs the fp32 oracle (tests/test_gpu_parity.py)
+# Bounds = about 3x what MI355X measured (DESIGN.md section 3 lists the observed values):
+ROW_VS_BATCH = 1e-3        # same math on different kernels, encoder / projector outputs (observed 1.2e-4 .. 2.3e-4)
+ROW_VS_BATCH_LOGITS = 3e-3 # ... and logits behind 32-40 decoder layers of fp16 hand-offs (observed 8.8e-4 .. 9.3e-4)
+ORACLE_POOLED = 1e-3       # fp16-operand HIP path vs the fp32 oracle: pooled embedding, 33 layers (observed 1.2e-4 .. 2.4e-4)
+ORACLE_PROT = 2e-3         # protein tokens (observed 4.4e-4 .. 5.0e-4)
+ORACLE_LOGITS = 3e-3       # logits, 32 layers (observed 7.0e-4 .. 8.9e-4)
 
 
 def _model(cfg, dev):
@@ -96,7 +100,7 @@ def _row_vs_batch(model, cfg, seqs, ids, rows, tag):
                 assert int(one[s, 0].argmax()) == int(steps[s, i].argmax()), (tag, i, s)
     record(tag + ".row_vs_batch", dict(worst, decisive_steps=decisive, steps=checked))
     assert worst["pooled"] < ROW_VS_BATCH and worst["prot"] < ROW_VS_BATCH, worst
-    assert worst["logits"] < 2.5 * ROW_VS_BATCH, worst          # 32 decoder layers of fp16 hand-offs on top
+    assert worst["logits"] < ROW_VS_BATCH_LOGITS, worst
     assert decisive >= checked // 2, (decisive, checked)        # the synthetic model is far from ties on most steps
     return pooled, prot, emb, mask, steps, forced
 
@@ -161,7 +165,7 @@ def test_b64_decode_step_agrees_with_prefill_of_longer_prompt(big64):
     ref = model.prefill_logits(emb2, mask2)
     rel = rel_l2(lg1, ref)
     record("b64.decode_vs_prefill", rel)
-    assert rel < 5e-3, rel
+    assert rel < 2e-3, rel                                      # observed 5.8e-4
     decisive = _margin(ref) > MARGIN_TAU
     assert torch.equal(lg1.argmax(-1)[decisive], ref.argmax(-1)[decisive])
     assert int(decisive.sum()) >= 48
@@ -224,7 +228,7 @@ def test_full_width_two_layer_batch64_vs_oracle(dev):
         prot_ref = pipe.switch_projector_embedding(pipe.encode_projector_embedding(pooled_ref))
         prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
         obs = dict(pooled=rel_l2(pooled, pooled_ref), prot=rel_l2(prot.float(), prot_ref))
-        assert obs["pooled"] < REL_L2 and obs["prot"] < 2 * REL_L2, obs
+        assert obs["pooled"] < ORACLE_POOLED and obs["prot"] < ORACLE_PROT, obs
         ref_ids, margins, ref_logits = pipe.generate(ids, seqs, mask, 5, (), 0)
         out = model.generate(ids, seqs, attention_mask=mask, pad_token_id=0, do_sample=False, max_new_tokens=5)
         n_ok = n_all = 0
@@ -239,8 +243,8 @@ def test_full_width_two_layer_batch64_vs_oracle(dev):
         got = _teacher_forced(model, emb, mo, ref_ids[:, :3].to(dev))
         obs["logits"] = [rel_l2(got[s], ref_logits[s]) for s in range(4)]
         record("full_width_b64_vs_oracle", obs)
-        assert max(obs["logits"]) < 2 * REL_L2, obs
-        assert obs["ids_checked_fraction"] >= 0.8, obs
+        assert max(obs["logits"]) < ORACLE_LOGITS, obs
+        assert obs["ids_checked_fraction"] >= 0.88, obs         # 282 of 320 ids lie before their row's first near-tie
     finally:
         del model
         torch.cuda.empty_cache()
@@ -281,8 +285,8 @@ def test_c2_full_depth_vs_oracle(big64):
     obs["logits"] = [rel_l2(got[s][0], ref[s]) for s in range(4)]
     obs["margins"] = [float(_margin(ref[s:s + 1])) for s in range(4)]
     record("c2_full_depth_vs_oracle", obs)
-    assert obs["pooled"] < REL_L2 and obs["prot"] < 2 * REL_L2, obs
-    assert max(obs["logits"]) < 2 * REL_L2, obs
+    assert obs["pooled"] < ORACLE_POOLED and obs["prot"] < ORACLE_PROT, obs
+    assert max(obs["logits"]) < ORACLE_LOGITS, obs
     for s in range(4):
         if obs["margins"][s] > MARGIN_TAU:
             assert int(got[s][0].argmax()) == int(ref[s].argmax()), (s, obs)
@@ -305,7 +309,7 @@ def test_c5_shape_properties(dev):
         ref = model.prefill_logits(emb2, mask2)
         rel = rel_l2(lg1, ref)
         record("c5.decode_vs_prefill", rel)
-        assert rel < 5e-3, rel
+        assert rel < 2e-3, rel                                  # observed 5.9e-4
         decisive = _margin(ref) > MARGIN_TAU
         assert torch.equal(lg1.argmax(-1)[decisive], ref.argmax(-1)[decisive])
         a = model.generate(ids, seqs, max_new_tokens=6, pad_token_id=0)
