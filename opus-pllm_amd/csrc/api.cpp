@@ -105,6 +105,8 @@ struct opus_ctx {
     // row-scale fusion (GemmParams::xh_out / row_ssq): one-shot request for the next gemm() and its outcome
     half_t *rq_xh = nullptr;
     int rq_done = 0;
+    // one-shot requests for the next gemm(): route a narrow output through the wide kernel / leave raw k-part slabs
+    int rq_force_wide = 0, rq_slab_only = 0, rq_ks = 1;
     const float *xh_src = nullptr;       // fp32 buffer whose fp16 copy + sum-of-squares partials are valid
     bool use_row_scale = false;          // one-shot: the next gemm() multiplies its rows by the rstd from d_ssq
     float *d_ssq = nullptr;
@@ -462,6 +464,9 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     c->rq_xh = nullptr;                  // one-shot
     p.row_ssq = nullptr; p.row_nblk = 0;
     if (c->use_row_scale) { p.row_ssq = c->d_ssq; p.row_nblk = K >> 8; p.norm_eps = c->row_eps; c->use_row_scale = false; }
+    c->rq_ks = 1;
+    p.force_wide = c->rq_force_wide; p.slab_only = c->rq_slab_only; p.ks_out = &c->rq_ks;
+    c->rq_force_wide = c->rq_slab_only = 0;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     // algorithmic bytes: the weights once + activations in + result out (+ the residual read)
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
@@ -707,6 +712,28 @@ static int lm_head(opus_ctx *c, hipStream_t s, int B) {
 }
 
 
+// decode-step attention of layer l over the projection output in d_qkv (rows of the last prefill, T prompt positions)
+// (slab_ks > 0: the QKV GEMM left slab_ks raw k-part slabs in the GEMM workspace and the sums of squares of its input rows in
+// d_ssq: summed, scaled and biased by the attention kernel itself)
+static int attn_decode(opus_ctx *c, hipStream_t s, int l, int B, int T, int slab_ks = 0, const float *bias = nullptr) {
+    const opus_config &g = c->cfg;
+    AttnDecodeParams a;
+    a.qkv = c->d_qkv; a.slabs = nullptr; a.ks = 0; a.slab_stride = 0; a.row_ssq = nullptr; a.row_nblk = 0; a.eps = 0.f; a.K = 0;
+    a.bias = nullptr;
+    if (slab_ks > 0) {
+        const int64_t QKVd = (int64_t)(g.dec_heads + 2 * g.dec_kv_heads) * g.dec_head_dim;
+        a.qkv = nullptr; a.slabs = c->gemm_ws; a.ks = slab_ks; a.slab_stride = (int64_t)B * QKVd;
+        a.row_ssq = c->d_ssq; a.row_nblk = g.dec_dim >> 8; a.eps = g.dec_rms_eps; a.K = g.dec_dim; a.bias = bias;
+    }
+    a.cs = c->cs_dec; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = T; a.nh = g.dec_heads; a.nkv = g.dec_kv_heads;
+    a.kc = c->kc + l * c->cache_sl; a.vc = c->vc + l * c->cache_sl; a.cache_sb = c->cache_sb; a.cache_sh = c->cache_sh;
+    a.ctx_cap = g.max_prompt + g.max_new_tokens; a.scale = 1.0f / sqrtf((float)g.dec_head_dim); a.out = c->d_ctx;
+    // algorithmic bytes: the rows' K / V history once (+ the new token's q, k, v and the output)
+    const double bytes = 4.0 * B * g.dec_kv_heads * g.dec_head_dim * (T + 1) + 2.0 * B * (2.0 * g.dec_heads + 2.0 * g.dec_kv_heads) * g.dec_head_dim;
+    KL(KC_ATTN_DECODE, bytes, launch_attn_decode(a, B, g.dec_head_dim, s));
+    return OPUS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ OPT / Galactica decoder
 // transformers OPTDecoder with do_layer_norm_before (reference wrapper language_model/opus_opt.py:18-40):
 //   x = inputs_embeds + pos;  per layer  x += Wo attn(LN1 x) + bo;  x += W2 gelu(W1 LN2 x + b1) + b2;  logits = lm_head LNf x.
@@ -719,10 +746,7 @@ static int opt_layer(opus_ctx *c, hipStream_t s, const DecLayer &L, int l, float
     KL(KC_NORM, 6.0 * M * H, launch_layernorm(x, L.ln1w, L.ln1b, g.dec_rms_eps, M, H, xn, nullptr, s));
     OPC(gemm(c, s, xn, H, L.wqkv, M, QKV, H, L.bqkv, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
     if (decode) {
-        KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (T + 1),
-           launch_attn_decode(c->d_qkv, c->cs_dec, c->d_kstart, c->d_step, T, B, nh, nkv, hd, c->kc + l * c->cache_sl,
-                              c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, g.max_prompt + g.max_new_tokens,
-                              1.0f / sqrtf((float)hd), c->d_ctx, s));
+        OPC(attn_decode(c, s, l, B, T));
     } else {
         KL(KC_OTHER, 4.0 * M * QKV,
            launch_dec_rope_cache(c->d_qkv, c->cs_dec, c->d_kstart, B, T, nh, nkv, hd, c->kc + l * c->cache_sl,
@@ -844,7 +868,13 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
     const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
     const int ctx_cap = g.max_prompt + g.max_new_tokens;
-    KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, s));
+    // batched Llama / Qwen2 step: the embedding kernel also leaves fp16(x) and its per-block sums of squares, so that the first
+    // layer's QKV GEMM can take the row-scale RMSNorm form like every later one (whose producer is the previous down GEMM)
+    const bool rowscale = g.dec_arch == 0 && fuse_rows() && B > SKINNY_MAX_M && B <= MID_MAX_M && (H & 255) == 0 &&
+                          !(stack_enabled() && !g.dec_qkv_bias && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap));
+    KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, rowscale ? c->d_xln : nullptr,
+                                                  rowscale ? c->d_ssq : nullptr, s));
+    c->xh_src = rowscale ? c->d_xl : nullptr;
     if (g.dec_arch == 1) return decode_step_opt(c, s);
     if (stack_enabled() && !g.dec_qkv_bias && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap)) {
         c->stack_used = true;
@@ -872,16 +902,28 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     }
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
-        OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wqkv, B, QKV, H, EPI_NONE, c->d_qkv, QKV, 0, L.bqkv));
-        KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (T + 1),
-           launch_attn_decode(c->d_qkv, c->cs_dec, c->d_kstart, c->d_step, T, B, nh, nkv, hd, c->kc + l * c->cache_sl,
-                              c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, ctx_cap, 1.0f / sqrtf((float)hd),
-                              c->d_ctx, s));
+        if (rowscale && c->xh_src == c->d_xl) {
+            // x is available as fp16 + sums of squares (from the embedding or the previous layer's down GEMM): the QKV
+            // projection streams its weights through the wide kernel with k-parts and leaves the raw slabs; the attention
+            // kernel sums them, applies the RMSNorm row scale and the bias on the fly - no norm launch, no reduce launch
+            c->xh_src = nullptr;
+            c->rq_force_wide = 1;
+            c->rq_slab_only = 1;
+            c->use_row_scale = true;
+            c->row_eps = g.dec_rms_eps;
+            OPC(gemm(c, s, c->d_xln, H, L.wqkv, B, QKV, H, L.bqkv, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
+            OPC(attn_decode(c, s, l, B, T, c->rq_ks > 1 ? c->rq_ks : 0, L.bqkv));
+        } else {
+            OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wqkv, B, QKV, H, EPI_NONE, c->d_qkv, QKV, 0, L.bqkv));
+            OPC(attn_decode(c, s, l, B, T));
+        }
         if (fuse_rows() && B <= 96) c->rq_xh = c->d_xln;
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, B, H, QD, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
         c->xh_src = c->rq_done ? c->d_xl : nullptr;
         OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wgu, B, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
+        if (fuse_rows() && B <= 96) c->rq_xh = c->d_xln;
         OPC(gemm(c, s, c->d_act, F, L.wd, B, H, F, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
+        c->xh_src = c->rq_done ? c->d_xl : nullptr;
     }
     OPC(lm_head(c, s, B));
     KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));

@@ -1,11 +1,19 @@
-// Decode-step attention (row D3/D4): for one new token per batch row,
-//   rotary(q, k) at position slot - kstart[b]  ->  append k, v to the cache at `slot`  ->
-//   softmax(q K^T * scale over keys kstart[b]..slot) V.
-// Workgroup = GP query heads of one kv group of one batch row: GP = 1 at small batch (32 workgroups
-// per row instead of 8: the step is latency-bound, so spread it), GP = group at large batch (K/V of a
-// kv head are read once per row).  K/V go straight to registers (cdna_hip_programming.md Appendix B
-// "Attention decode"): two lanes per key for the scores, one 8-wide column slice per lane for PV.
-// The new key/value are used from LDS, so nothing depends on in-launch global visibility.
+// Decode-step attention (rows D3/D4): for one new token per batch row,
+//   [sum of the QKV GEMM's k-part slabs * rstd + bias] -> rotary(q, k) at position slot - kstart[b]
+//   -> append k, v to the cache at `slot` -> softmax(q K^T * scale over keys kstart[b]..slot) V.
+//
+// Workgroup = GP query heads of one kv group of one batch row (GP = 1 at small batch: 32 workgroups per row instead of 8 -
+// the step is latency-bound, so spread it; GP = group at large batch: K/V of a kv head are read once per row), 4 waves.
+// The keys are split over the WAVES in tiles of 32 and every wave runs its own online softmax ("flash decoding"): there is
+// no block-wide reduction inside the key loop - two barriers in the whole kernel (after the rotary staging, before the final
+// combine) instead of the eight of a block-wide max / sum / PV pipeline; that chain of barriers, not bytes, was the time.
+//   scores   S^T[key][head] = K[key][:] q[head][:]  MFMA 16x16x32: A = 16 cached keys x 32 dims straight from the cache
+//            (64 contiguous bytes per key and instruction), B = the rotated query heads from LDS (columns >= GP are zero)
+//   softmax  per head = per MFMA column: 8 scores per lane, combined over the four 16-lane groups with two xor-shuffles
+//   P V      lane = (8-wide slice of the head dim, group of 32 / KPN keys): V rows are read with fully coalesced 16-B loads,
+//            P comes back from a wave-private LDS patch (consecutive probabilities per lane)
+//   combine  (m, l, O) of the 4 waves x KPN key groups through LDS, one pass.
+// The new key / value are used from LDS, so nothing depends on in-launch global visibility.
 // slot = T0 + *step is read from device memory so the same launch can be replayed from a hipGraph.
 #include "common.h"
 #include <cstdlib>
@@ -14,86 +22,96 @@ namespace opus {
 
 constexpr int MAXG = 8;
 
-__device__ __forceinline__ float block_reduce(float v, bool is_max, float *scratch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = __shfl_xor(v, o, 64);
-        v = is_max ? fmaxf(v, t) : v + t;
-    }
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    float r = scratch[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, scratch[w]) : r + scratch[w];
-    return r;
-}
-
 template <int HD, int GP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restrict__ qkv, const float *__restrict__ cs,
-                                                          const int32_t *__restrict__ kstart_p,
-                                                          const int32_t *__restrict__ step_p, int T0, int nh, int nkv,
-                                                          half_t *__restrict__ kc, half_t *__restrict__ vc,
-                                                          int64_t cache_sb, int64_t cache_sh, int ctx_cap, float scale,
-                                                          half_t *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int HALF = HD / 2, DV = HD / 8, PARTS = 256 / DV, HC = DV / 2;
-    const int G = nh / nkv;
-    float *sq = sm;                       // [GP][HD]   rotated query heads (fp16-rounded)
-    float *sk = sq + GP * HD;             // [HD]       rotated new key
-    float *sv = sk + HD;                  // [HD]       new value
-    float *sc = sv + HD;                  // [GP][ctx_cap]
-    float *red = sc + GP * ctx_cap;       // [PARTS][GP][HD]
-    __shared__ float scratch[4];
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    constexpr int HALF = HD / 2;
+    constexpr int HDP = HD < 32 ? 32 : HD;          // k extent of the score MFMAs (zero-padded for head_dim 16)
+    constexpr int KS = HDP / 32;                    // MFMA k-steps per 16-key subtile
+    constexpr int DV = HD / 8;                      // 16-B slices per K / V row
+    constexpr int KPN = 64 / DV;                    // key groups of the PV lanes
+    constexpr int KPK = 32 / KPN;                   // keys per group and tile
+    // dynamic LDS: [sq fp16 GP x HDP][sk fp16 HDP][sv fp16 HDP][pw 4 x GP x 32 f32][stats 4 x GP x 2 f32][red 4 KPN x GP x HD f32]
+    half_t *sq = reinterpret_cast<half_t *>(smraw);
+    half_t *sk = sq + GP * HDP;
+    half_t *sv = sk + HDP;
+    float *pw = reinterpret_cast<float *>(sv + HDP);
+    float *stats = pw + 4 * GP * 32;
+    float *red = stats + 4 * GP * 2;
 
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int h0 = blockIdx.x * GP;       // first query head of this workgroup
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int G = p.nh / p.nkv;
+    const int h0 = blockIdx.x * GP;                 // first query head of this workgroup
     const int kvh = h0 / G;
-    const bool writer = (h0 % G) == 0;    // one workgroup per kv head appends to the cache
-    const int slot = T0 + *step_p;
-    const int kstart = kstart_p[b];
+    const bool writer = (h0 % G) == 0;              // one workgroup per kv head appends to the cache
+    const int slot = p.T0 + *p.step;
+    const int kstart = p.kstart[b];
     const int pos = slot - kstart;
-    const int64_t ld = (int64_t)(nh + 2 * nkv) * HD;
-    const half_t *row = qkv + (int64_t)b * ld;
-    half_t *kcb = kc + b * cache_sb + kvh * cache_sh;
-    half_t *vcb = vc + b * cache_sb + kvh * cache_sh;
+    const int ncached = slot - kstart;              // cached keys kstart .. slot-1; the new key comes from LDS
+    const int64_t ld = (int64_t)(p.nh + 2 * p.nkv) * HD;
+    half_t *kcb = p.kc + b * p.cache_sb + kvh * p.cache_sh;
+    half_t *vcb = p.vc + b * p.cache_sb + kvh * p.cache_sh;
+    const int ntiles = (ncached + 31) >> 5;
+    const int new_wave = ntiles & 3;                // the wave with the fewest tiles also takes the new key
 
-    // ---- prefetch: the cached K rows of the first 128 keys (two lanes per key) and the first VP value rows of
-    // this thread's key partition are requested BEFORE the rotary / staging phase, so the three dependent
-    // global-memory round trips of the step (q/k/v row, K, V) overlap into one.
-    const int nkeys = slot - kstart + 1;
-    const int hh = tid & 1;
-    constexpr int VP = 8;
-    const int dv = tid % DV, part = tid / DV;
-    h8 kpre[HC], vpre[VP];
-    {
-        const int j = tid >> 1;
-        const int jc = j < nkeys - 1 ? j : 0;
-        const h8 *kr = reinterpret_cast<const h8 *>(kcb + (int64_t)(kstart + jc) * HD) + hh * HC;
+    // ---- prefetch this wave's first tile (K fragments + V rows) before the rotary / staging phase: the dependent global
+    // round trips of the step (q/k/v row, K, V) overlap into one
+    h8 kf[2][KS], vr[KPK];
+    const int dv = lane % DV, kp = lane / DV;
+    auto load_tile = [&](int t) {
+        const int j0 = 32 * t;
 #pragma unroll
-        for (int c = 0; c < HC; ++c) kpre[c] = kr[c];
+        for (int a = 0; a < 2; ++a) {
+            int j = j0 + 16 * a + li;
+            j = j < ncached ? j : (ncached > 0 ? ncached - 1 : 0);
+            const half_t *kr = kcb + (int64_t)(kstart + j) * HD;
 #pragma unroll
-        for (int u = 0; u < VP; ++u) {
-            const int jv = part + u * PARTS;
-            const int jvc = jv < nkeys - 1 ? jv : 0;
-            vpre[u] = *reinterpret_cast<const h8 *>(vcb + (int64_t)(kstart + jvc) * HD + dv * 8);
+            for (int s = 0; s < KS; ++s) {
+                const int d = 32 * s + 8 * g;
+                kf[a][s] = d < HD ? *reinterpret_cast<const h8 *>(kr + d) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
-    }
+#pragma unroll
+        for (int i = 0; i < KPK; ++i) {
+            int j = j0 + KPK * kp + i;
+            j = j < ncached ? j : (ncached > 0 ? ncached - 1 : 0);
+            vr[i] = *reinterpret_cast<const h8 *>(vcb + (int64_t)(kstart + j) * HD + dv * 8);
+        }
+    };
+    if (wave < ntiles) load_tile(wave);
 
-    // ---- rotary on the query heads and the new key; stage k, v ----
+    // ---- the new token's q / k / v (optionally: sum of the QKV GEMM's k-part slabs, RMSNorm row scale, bias), rotary on
+    // the query heads and the key; stage them in LDS and append k, v to the cache ----
+    float rstd = 1.0f;
+    if (p.row_ssq) {
+        float q = 0.f;
+        for (int j = 0; j < p.row_nblk; ++j) q += p.row_ssq[b * p.row_nblk + j];
+        rstd = rsqrtf(q / (float)p.K + p.eps);
+    }
+    auto elem = [&](int64_t col) -> float {         // projection output (b, col) rounded to fp16, as the unfused GEMM stores it
+        if (p.slabs) {
+            float v = 0.f;
+            for (int k = 0; k < p.ks; ++k) v += p.slabs[k * p.slab_stride + b * ld + col];
+            v *= rstd;
+            if (p.bias) v += p.bias[col];
+            return (float)(half_t)v;
+        }
+        return (float)p.qkv[b * ld + col];
+    };
     for (int i = tid; i < (GP + 1) * HALF; i += 256) {
         const int j = i / HALF, d = i % HALF;
-        const half_t *src = j < GP ? row + (int64_t)(h0 + j) * HD : row + (int64_t)(nh + kvh) * HD;
-        const float c = cs[((int64_t)pos * HALF + d) * 2], sn = cs[((int64_t)pos * HALF + d) * 2 + 1];
-        const float a = (float)src[d], bb = (float)src[d + HALF];
+        const int64_t col = j < GP ? (int64_t)(h0 + j) * HD : (int64_t)(p.nh + kvh) * HD;
+        const float c = p.cs[((int64_t)pos * HALF + d) * 2], sn = p.cs[((int64_t)pos * HALF + d) * 2 + 1];
+        const float a = elem(col + d), bb = elem(col + d + HALF);
         const half_t lo = (half_t)(a * c - bb * sn), hi = (half_t)(bb * c + a * sn);
         if (j < GP) {
-            sq[j * HD + d] = (float)lo;
-            sq[j * HD + d + HALF] = (float)hi;
+            sq[j * HDP + d] = lo;
+            sq[j * HDP + d + HALF] = hi;
         } else {
-            sk[d] = (float)lo;
-            sk[d + HALF] = (float)hi;
+            sk[d] = lo;
+            sk[d + HALF] = hi;
             if (writer) {
                 kcb[(int64_t)slot * HD + d] = lo;
                 kcb[(int64_t)slot * HD + d + HALF] = hi;
@@ -101,194 +119,182 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const half_t *__restri
         }
     }
     for (int d = tid; d < HD; d += 256) {
-        const half_t v = row[(int64_t)(nh + nkv + kvh) * HD + d];
-        sv[d] = (float)v;
+        const half_t v = (half_t)elem((int64_t)(p.nh + p.nkv + kvh) * HD + d);
+        sv[d] = v;
         if (writer) vcb[(int64_t)slot * HD + d] = v;
     }
-    __syncthreads();
-
-    // ---- scores: two lanes per key (each half of the head dim), cached keys then the new one ----
-    for (int j0 = 0; j0 < nkeys; j0 += 128) {
-        const int j = j0 + (tid >> 1);
-        float acc[GP];
-#pragma unroll
-        for (int gi = 0; gi < GP; ++gi) acc[gi] = 0.f;
-        if (j < nkeys - 1) {
-            h8 kv[HC];
-            if (j0 == 0) {
-#pragma unroll
-                for (int c = 0; c < HC; ++c) kv[c] = kpre[c];
-            } else {
-                const h8 *kr = reinterpret_cast<const h8 *>(kcb + (int64_t)(kstart + j) * HD) + hh * HC;
-#pragma unroll
-                for (int c = 0; c < HC; ++c) kv[c] = kr[c];
-            }
-#pragma unroll
-            for (int c = 0; c < HC; ++c)
-#pragma unroll
-                for (int gi = 0; gi < GP; ++gi)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[gi] += (float)kv[c][e] * sq[gi * HD + (hh * HC + c) * 8 + e];
-        } else if (j == nkeys - 1) {
-#pragma unroll
-            for (int c = 0; c < HC; ++c)
-#pragma unroll
-                for (int gi = 0; gi < GP; ++gi)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        acc[gi] += sk[(hh * HC + c) * 8 + e] * sq[gi * HD + (hh * HC + c) * 8 + e];
-        }
-#pragma unroll
-        for (int gi = 0; gi < GP; ++gi) {
-            const float t = acc[gi] + __shfl_xor(acc[gi], 1, 64);
-            if (hh == 0 && j < nkeys) sc[gi * ctx_cap + j] = t * scale;
+    if (HD < HDP) {                                  // zero padding of the 32-wide MFMA k extent
+        for (int i = tid; i < (GP + 1) * (HDP - HD); i += 256) {
+            const int j = i / (HDP - HD), d = HD + i % (HDP - HD);
+            if (j < GP) sq[j * HDP + d] = (half_t)0.f;
+            else sk[d] = (half_t)0.f;
         }
     }
     __syncthreads();
 
-    // ---- softmax per head (fp32); the GP heads share each block-wide reduction (2 barriers instead of 2 GP) ----
-    float linv[GP], mx[GP], sum[GP];
-    __shared__ float redv[4][GP];
-    auto reduce_all = [&](float (&v)[GP], bool is_max) {
+    // query fragments: B operand, column li = head (zero beyond GP)
+    h8 qf[KS];
 #pragma unroll
-        for (int gi = 0; gi < GP; ++gi) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float t = __shfl_xor(v[gi], o, 64);
-                v[gi] = is_max ? fmaxf(v[gi], t) : v[gi] + t;
-            }
-        }
-        __syncthreads();
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int gi = 0; gi < GP; ++gi) redv[tid >> 6][gi] = v[gi];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int gi = 0; gi < GP; ++gi) {
-            float r = redv[0][gi];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, redv[w][gi]) : r + redv[w][gi];
-            v[gi] = r;
-        }
-    };
-#pragma unroll
-    for (int gi = 0; gi < GP; ++gi) {
-        mx[gi] = -INFINITY;
-        for (int j = tid; j < nkeys; j += 256) mx[gi] = fmaxf(mx[gi], sc[gi * ctx_cap + j]);
-    }
-    reduce_all(mx, true);
-#pragma unroll
-    for (int gi = 0; gi < GP; ++gi) {
-        sum[gi] = 0.f;
-        for (int j = tid; j < nkeys; j += 256) {
-            const float e = __expf(sc[gi * ctx_cap + j] - mx[gi]);
-            // P is rounded to fp16 before the PV product, as the prefill kernel and HF (softmax .to(q.dtype))
-            sc[gi * ctx_cap + j] = (float)(half_t)e;
-            sum[gi] += e;
-        }
-    }
-    reduce_all(sum, false);
-#pragma unroll
-    for (int gi = 0; gi < GP; ++gi) linv[gi] = 1.0f / sum[gi];
-    __syncthreads();
+    for (int s = 0; s < KS; ++s)
+        qf[s] = li < GP ? *reinterpret_cast<const h8 *>(sq + li * HDP + 32 * s + 8 * g) : h8{0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- O = P V : thread = (8-wide column slice, key partition) ----
+    float m_run = -INFINITY, l_run = 0.f;            // per lane: head li, its own keys (l is summed over g at the end)
     float acc[GP][8];
 #pragma unroll
-    for (int gi = 0; gi < GP; ++gi)
+    for (int h = 0; h < GP; ++h)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[gi][e] = 0.f;
+        for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+    float *myp = pw + wave * GP * 32;
+
+    // one tile of up to 32 keys: nvalid visible keys; K fragments in kf, V rows in vr
+    auto tile = [&](int nvalid) {
+        f4 s2[2];
 #pragma unroll
-    for (int u = 0; u < VP; ++u) {
-        const int j = part + u * PARTS;
-        if (j < nkeys - 1) {
+        for (int a = 0; a < 2; ++a) {
+            s2[a] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int gi = 0; gi < GP; ++gi) {
-                const float pj = sc[gi * ctx_cap + j];
+            for (int s = 0; s < KS; ++s) s2[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[a][s], qf[s], s2[a], 0, 0, 0);
+        }
+        // lane (li = head, g): s2[a][r] = score of key 16a + 4g + r
+        float mx = -INFINITY;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[gi][e] += pj * (float)vpre[u][e];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (16 * a + 4 * g + r) < nvalid ? s2[a][r] * p.scale : -INFINITY;
+                s2[a][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);        // nvalid >= 1: finite
+        const float alpha = __expf(m_run - m_new);   // 0 on the first tile
+        float ps = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f4 pv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // P is rounded to fp16 before the PV product, as the prefill kernel and HF (softmax .to(q.dtype))
+                const float e = __expf(s2[a][r] - m_new);
+                ps += e;
+                pv[r] = (float)(half_t)e;
+            }
+            if (li < GP) *reinterpret_cast<f4 *>(myp + li * 32 + 16 * a + 4 * g) = pv;
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        // same-wave LDS round trip (in-order LDS queue); the fences keep the compiler from reordering across it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < GP; ++h) {
+            const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), h));
+            float pj[KPK];
+#pragma unroll
+            for (int i = 0; i < KPK; ++i) pj[i] = myp[h * 32 + KPK * kp + i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = acc[h][e] * al;
+#pragma unroll
+                for (int i = 0; i < KPK; ++i) o += pj[i] * (float)vr[i][e];
+                acc[h][e] = o;
             }
         }
+        // the patch is rewritten by the next tile: its reads above must have retired (same wave, in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    for (int t = wave; t < ntiles; t += 4) {
+        if (t != wave) load_tile(t);
+        const int left = ncached - 32 * t;
+        tile(left < 32 ? left : 32);
     }
-    for (int j = part + VP * PARTS; j < nkeys - 1; j += PARTS) {
-        const h8 vv = *reinterpret_cast<const h8 *>(vcb + (int64_t)(kstart + j) * HD + dv * 8);
+    if (wave == new_wave) {                          // the new key / value: a one-key tile fed from LDS
 #pragma unroll
-        for (int gi = 0; gi < GP; ++gi) {
-            const float pj = sc[gi * ctx_cap + j];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[gi][e] += pj * (float)vv[e];
-        }
+            for (int s = 0; s < KS; ++s)
+                kf[a][s] = (a == 0 && li == 0) ? *reinterpret_cast<const h8 *>(sk + 32 * s + 8 * g) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < KPK; ++i)
+            vr[i] = (i == 0 && kp == 0) ? *reinterpret_cast<const h8 *>(sv + dv * 8) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+        tile(1);
     }
-    if (part == (nkeys - 1) % PARTS) {
-#pragma unroll
-        for (int gi = 0; gi < GP; ++gi) {
-            const float pj = sc[gi * ctx_cap + nkeys - 1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[gi][e] += pj * sv[dv * 8 + e];
-        }
+
+    // ---- publish (m, l) per head and the partial outputs; combine ----
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (g == 0 && li < GP) {
+        stats[(wave * GP + li) * 2] = m_run;
+        stats[(wave * GP + li) * 2 + 1] = l_run;
     }
 #pragma unroll
-    for (int gi = 0; gi < GP; ++gi)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(part * GP + gi) * HD + dv * 8 + e] = acc[gi][e];
+    for (int h = 0; h < GP; ++h) {
+        float *dst = red + ((int64_t)((wave * KPN + kp) * GP + h)) * HD + dv * 8;
+        *reinterpret_cast<f4 *>(dst) = f4{acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
+        *reinterpret_cast<f4 *>(dst + 4) = f4{acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
+    }
     __syncthreads();
     for (int i = tid; i < GP * HD; i += 256) {
-        const int gi = i / HD, d = i % HD;
-        float s = 0.f;
-        for (int pp = 0; pp < PARTS; ++pp) s += red[(pp * GP + gi) * HD + d];
-        float li = linv[0];
+        const int h = i / HD, d = i % HD;
+        float M = -INFINITY;
 #pragma unroll
-        for (int q = 1; q < GP; ++q) li = (q == gi) ? linv[q] : li;
-        out[(int64_t)b * nh * HD + (int64_t)(h0 + gi) * HD + d] = (half_t)(s * li);
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, stats[(w * GP + h) * 2]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = stats[(w * GP + h) * 2];
+            const float f = mw == -INFINITY ? 0.f : __expf(mw - M);
+            float s = 0.f;
+            for (int q = 0; q < KPN; ++q) s += red[((int64_t)((w * KPN + q) * GP + h)) * HD + d];
+            num += f * s;
+            den += f * stats[(w * GP + h) * 2 + 1];
+        }
+        p.out[(int64_t)b * p.nh * HD + (int64_t)(h0 + h) * HD + d] = (half_t)(num / den);
     }
 }
 
 template <int HD, int GP>
-static hipError_t launch_t(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int B,
-                           int nh, int nkv, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh, int ctx_cap,
-                           float scale, half_t *out, hipStream_t s) {
-    const int parts = 256 / (HD / 8);
-    const size_t lds = ((size_t)GP * HD + 2 * HD + (size_t)GP * ctx_cap + (size_t)parts * GP * HD) * sizeof(float);
+static hipError_t launch_t(const AttnDecodeParams &p, int B, hipStream_t s) {
+    constexpr int HDP = HD < 32 ? 32 : HD, KPN = 64 / (HD / 8);
+    const size_t lds = (size_t)(GP * HDP + 2 * HDP) * sizeof(half_t) +
+                       ((size_t)4 * GP * 32 + 4 * GP * 2 + (size_t)4 * KPN * GP * HD) * sizeof(float);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&attn_decode_kernel<HD, GP>), lds);
         if (ea != hipSuccess) return ea;
     }
-    OPUS_LAUNCH(KC_ATTN_DECODE, (attn_decode_kernel<HD, GP>), dim3(nh / GP, B), dim3(256), lds, s, qkv, cs, kstart, step, T0, nh,
-                       nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out);
+    OPUS_LAUNCH(KC_ATTN_DECODE, (attn_decode_kernel<HD, GP>), dim3(p.nh / GP, B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
 template <int HD>
-static hipError_t launch_hd(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int B,
-                            int nh, int nkv, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh, int ctx_cap,
-                            float scale, half_t *out, hipStream_t s) {
-    const int G = nh / nkv;
+static hipError_t launch_hd(const AttnDecodeParams &p, int B, hipStream_t s) {
+    const int G = p.nh / p.nkv;
     // grouped form only when the per-head form would already fill the chip several times over
     static const int group_min = getenv("OPUS_ATTN_GROUP_MIN") ? atoi(getenv("OPUS_ATTN_GROUP_MIN")) : 256;   // tuning aid
-    const bool grouped = G > 1 && (int64_t)B * nkv >= group_min;
-#define OPUS_GO(GPV) return launch_t<HD, GPV>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s)
-    if (!grouped) OPUS_GO(1);
+    const bool grouped = G > 1 && (int64_t)B * p.nkv >= group_min;
+    if (!grouped) return launch_t<HD, 1>(p, B, s);
     switch (G) {
-        case 2: OPUS_GO(2);
-        case 4: OPUS_GO(4);
-        case 8: OPUS_GO(8);
+        case 2: return launch_t<HD, 2>(p, B, s);
+        case 4: return launch_t<HD, 4>(p, B, s);
+        case 8: return launch_t<HD, 8>(p, B, s);
     }
-    OPUS_GO(1);
-#undef OPUS_GO
+    return launch_t<HD, 1>(p, B, s);
 }
 
-hipError_t launch_attn_decode(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step, int T0,
-                              int B, int nh, int nkv, int hd, half_t *kc, half_t *vc, int64_t cache_sb,
-                              int64_t cache_sh, int ctx_cap, float scale, half_t *out, hipStream_t s) {
-    const int G = nh / nkv;
-    if (G > MAXG || G * nkv != nh) return hipErrorInvalidValue;
+hipError_t launch_attn_decode(const AttnDecodeParams &p, int B, int hd, hipStream_t s) {
+    const int G = p.nh / p.nkv;
+    if (G > MAXG || G * p.nkv != p.nh) return hipErrorInvalidValue;
     switch (hd) {
-        case 16: return launch_hd<16>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
-        case 32: return launch_hd<32>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
-        case 64: return launch_hd<64>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
-        case 128: return launch_hd<128>(qkv, cs, kstart, step, T0, B, nh, nkv, kc, vc, cache_sb, cache_sh, ctx_cap, scale, out, s);
+        case 16: return launch_hd<16>(p, B, s);
+        case 32: return launch_hd<32>(p, B, s);
+        case 64: return launch_hd<64>(p, B, s);
+        case 128: return launch_hd<128>(p, B, s);
     }
     return hipErrorInvalidValue;
 }

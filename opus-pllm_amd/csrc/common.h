@@ -80,6 +80,12 @@ struct GemmParams {
     int *fused_done;
     const float *row_ssq;
     int row_nblk;
+    // slab_only: when the launch splits K over workgroups, leave the raw fp32 k-part slabs in ws ([ks][M][N], no epilogue) and
+    // report their number in *ks_out instead of launching the reduce - the consumer (attn_decode_kernel) sums them, applies the
+    // row scale and the bias itself; *ks_out = 1 means the kernel wrote the finished output as usual.
+    int slab_only = 0;
+    int *ks_out = nullptr;
+    int force_wide = 0;     // route a narrow output (N < 16384) through gemm_wide_kernel + k-parts
 };
 
 // Flash-style attention over strided Q/K/V (fp16).  Q(b,h,t,:) = Q + b*q_sb + t*q_st + h*HD etc.;
@@ -118,7 +124,10 @@ hipError_t launch_dec_rope_cache(half_t *qkv, const float *cs, const int32_t *ks
                                  int nkv, int hd, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh,
                                  hipStream_t s);
 hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s);
-hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, hipStream_t s);
+// x[b,:] = fp32(emb[tok[b]]); optionally also the fp16 copy xh and the per-256-column sums of squares ssq[b][H/256] (the
+// producer side of the row-scale RMSNorm fusion, GemmParams::row_ssq)
+hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
+                               hipStream_t s);
 hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, const int32_t *step, int t0, int B, int Tq,
                           int H, int max_idx, hipStream_t s);
 hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s);
@@ -144,9 +153,28 @@ hipError_t launch_step_advance(int32_t *step, hipStream_t s);
 hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kstart, hipStream_t s);
 
 // attn_decode.hip : rope(q,k at the new slot) + cache append + single-query attention
-hipError_t launch_attn_decode(const half_t *qkv, const float *cs, const int32_t *kstart, const int32_t *step,
-                              int T0, int B, int nh, int nkv, int hd, half_t *kc, half_t *vc, int64_t cache_sb,
-                              int64_t cache_sh, int ctx_cap, float scale, half_t *out, hipStream_t s);
+struct AttnDecodeParams {
+    const half_t *qkv;          // [B][(nh + 2 nkv) hd] fp16 projection output of the new tokens, or nullptr when slabs != nullptr
+    // fused split-K reduce of the QKV GEMM: element (b, col) = (sum_k slabs[k * slab_stride + b * ld + col]) * rstd(b) + bias[col],
+    // rstd(b) = rsqrt(sum_j row_ssq[b * row_nblk + j] / K + eps) when row_ssq != nullptr (the fused RMSNorm row scale), else 1
+    const float *slabs;
+    int ks;
+    int64_t slab_stride;
+    const float *row_ssq;
+    int row_nblk;
+    float eps;
+    int K;
+    const float *bias;
+    const float *cs;            // rotary table
+    const int32_t *kstart, *step;
+    int T0, nh, nkv;
+    half_t *kc, *vc;            // this layer's cache
+    int64_t cache_sb, cache_sh;
+    int ctx_cap;
+    float scale;
+    half_t *out;                // [B][nh hd]
+};
+hipError_t launch_attn_decode(const AttnDecodeParams &p, int B, int hd, hipStream_t s);
 
 // decode_stack.hip : the whole decoder stack + lm_head of one decode step in one persistent launch (batch <= 4)
 constexpr int STACK_MAX_B = 4;

@@ -174,9 +174,12 @@ hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, co
     return hipGetLastError();
 }
 
-// x[b,:] = fp32(emb[tok[b]]) : embedding of the token just generated (input of the next decode step)
+// x[b,:] = fp32(emb[tok[b]]) : embedding of the token just generated (input of the next decode step).  With xh / ssq
+// (H % 256 == 0) the row is also left as fp16 together with the sum of squares of each 256-column block: what the row-scale
+// RMSNorm fusion of the first layer's QKV GEMM consumes (GemmParams::row_ssq).
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__restrict__ tok, const half_t *__restrict__ emb,
-                                                           int H, int V, float *__restrict__ x) {
+                                                           int H, int V, float *__restrict__ x, half_t *__restrict__ xh,
+                                                           float *__restrict__ ssq) {
     const int b = blockIdx.x;
     int id = tok[b];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
@@ -185,10 +188,22 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__rest
         float4 *o = reinterpret_cast<float4 *>(x + (int64_t)b * H + c * 8);
         o[0] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
         o[1] = make_float4((float)e[4], (float)e[5], (float)e[6], (float)e[7]);
+        if (xh) {
+            *reinterpret_cast<h8 *>(xh + (int64_t)b * H + c * 8) = e;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q += (float)e[j] * (float)e[j];
+            // 32 consecutive threads hold one 256-column block (c / 32 is uniform over each half wave)
+#pragma unroll
+            for (int o2 = 16; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2, 64);
+            if ((threadIdx.x & 31) == 0) ssq[(int64_t)b * (H >> 8) + (c >> 5)] = q;
+        }
     }
 }
-hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, hipStream_t s) {
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x);
+hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
+                               hipStream_t s) {
+    if (xh && (H & 255)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x, xh, ssq);
     return hipGetLastError();
 }
 

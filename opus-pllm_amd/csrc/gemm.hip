@@ -1208,6 +1208,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
         float q = 0.f;
         for (int k = 0; k < ksplit; ++k) q += p.ws[ksplit * slab + (int64_t)k * p.M + m];
         rstd = rsqrtf(q / (float)p.K + p.norm_eps);
+    } else if (p.row_ssq) {   // row-scale fusion: the producer of A left per-block sums of squares of its rows
+        float q = 0.f;
+        for (int j = 0; j < p.row_nblk; ++j) q += p.row_ssq[m * p.row_nblk + j];
+        rstd = rsqrtf(q / (float)p.K + p.norm_eps);
     }
     float v;
     if (EPI == EPI_SILU_GU16) {
@@ -1481,19 +1485,20 @@ template <int MT, int EPI>
 static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
     const int blocks = cdiv((p.N + 15) >> 4, 8), chunks = p.K / 64;
     int ks = 1;
-    if (p.ws && blocks < 200 && !p.row_ssq) {                        // few column groups: split K over workgroups
+    if (p.ws && blocks < 200) {                                      // few column groups: split K over workgroups
         ks = cdiv(256, blocks);
         ks = ks > 8 ? 8 : ks;
         if (ks > chunks / 8) ks = chunks / 8;
         while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
         if (ks < 1) ks = 1;
     }
+    if (p.ks_out) *p.ks_out = ks;
     const int lds = 2 * (MT <= 4 ? 8 : 4) * 16 * MT * 128;
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_wide_kernel<MT, EPI>), lds);
     if (ea != hipSuccess) return ea;
     OPUS_LAUNCH(KC_WIDE, (gemm_wide_kernel<MT, EPI>), dim3(blocks, ks), dim3(512), lds, s, p, ks);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || ks == 1) return e;
+    if (e != hipSuccess || ks == 1 || p.slab_only) return e;
     return launch_reduce<EPI>(p, ks, s);
 }
 
@@ -1590,6 +1595,13 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     return launch_reduce<EPI>(p, ks, s);
 }
 
+// A/B aid: OPUS_NARROW_WIDE=1 routes every narrow GEMM at 5..64 rows (wo / down / qkv of the batched decode step) through
+// gemm_wide_kernel + k-parts instead of the mid / ring kernels
+static bool narrow_wide() {
+    static const bool v = getenv("OPUS_NARROW_WIDE") != nullptr;
+    return v;
+}
+
 int skinny_max_m() {
     static const int v = [] {
         const char *e = getenv("OPUS_SKINNY_MAX_M");
@@ -1628,7 +1640,7 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
             case EPI_GELU: return launch_skinny_e<EPI_GELU, false>(p, s);
             case EPI_SILU_GU16: return launch_skinny_e<EPI_SILU_GU16, false>(p, s);
         }
-    } else if (mid && !p.Af && !mid_v1 && p.N >= 16384) {
+    } else if (mid && !p.Af && !mid_v1 && (p.N >= 16384 || p.force_wide || narrow_wide())) {
         // wide outputs (wgu, lm_head): one barrier per 512 k, weights through per-wave register rings
         const bool m2 = p.M <= 32;
         switch (p.epi) {
