@@ -243,6 +243,35 @@ def roofline(model, work, dev):
     return res
 
 
+def projector_stage(model, cfg, dev, rows=1024, reps=5):
+    """The batched projector stage of the two-stage pipeline (eval_ddp.py --use_input_embed ->
+    model.project_dataset): `rows` pooled embeddings through P1 + P2 in one call, M = rows >= 512, where the switch-projector
+    GEMMs (5120 -> 8H, 8H -> 8H) are MFMA-bound.  north_star's ">= 50 % MFMA roofline on the projector GEMM" is read here:
+    per-launch dispatch timestamps of the product's own call, FLOPs = 2 M N K of the launches of the phase."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(11)
+    pooled = torch.randn(rows, cfg.enc_dim, generator=g).to(dev)
+    model.project_dataset(pooled)                                  # warm-up
+    torch.cuda.synchronize(dev)
+    model.timing(True)
+    for _ in range(reps):
+        model.project_dataset(pooled)
+    torch.cuda.synchronize(dev)
+    classes, _ = model.timing_names()
+    per = {k: model.timing_get(k, "project") for k in classes}
+    model.timing(False)
+    gemm = {k: v for k, v in per.items() if k.startswith("gemm_") and v[1]}
+    ms = sum(v[0] for v in gemm.values()); fl = sum(v[3] for v in gemm.values())
+    big = max(gemm, key=lambda k: gemm[k][3])
+    ach = fl / (ms * 1e-3) / 1e12
+    b_ms, b_n, _, b_fl = gemm[big]
+    return {"rows": rows, "calls": reps, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / MFMA_PEAK_TFLOPS, "gemm_ms_per_call": ms / reps,
+            "dominant_kernel": big, "dominant_tflops": b_fl / (b_ms * 1e-3) / 1e12, "dominant_avg_launch_us": 1e3 * b_ms / b_n,
+            "note": "all GEMM launches of model.project_dataset(rows x enc_dim): protein projector + switch projector (5120 -> 8H "
+                    "GELU, 8H -> 8H); algorithmic FLOPs 2 M N K over summed dispatch durations"}
+
+
 def cpu_baseline(cfg, residues, n_text, n_new, batch):
     """The oracle (CPU fp32 port of the reference path) timed on this host's cores on a bounded sample of the workload:
     ONE protein of the batch through the full-depth encoder + projectors + full-depth prefill + 4 decode steps,
@@ -389,10 +418,13 @@ def main():
         # every rank runs the (collective-free) measurement pass, rank 0 reports it
         r_main = roofline(model, main_work, dev)
         r_c2 = roofline(model, c2_work, dev) if c2_work is not None else None
+        r_proj = projector_stage(model, cfg, dev) if a.model in ("llama3_8b", "vicuna_13b") else None
         if rank == 0:
             res["roofline"] = r_main
             if r_c2 is not None:
                 res["c2"]["roofline"] = r_c2
+            if r_proj is not None:
+                res["projector_stage"] = r_proj
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not dry and not a.no_cpu_baseline:

@@ -20,6 +20,10 @@ SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "attn_prefill.hip", "attn_
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# Per-source flags.  The attention kernels run softmax arithmetic on the MFMA results between every two products: with the
+# accumulators in AGPRs (the compiler's default choice) each tile pays ~200 v_accvgpr_read / _write copies; gfx950's unified
+# register file lets MFMA use VGPRs for C / D directly.
+EXTRA = {"attn_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _deps_mtime() -> float:
@@ -31,9 +35,10 @@ def _deps_mtime() -> float:
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, src + ".o")
     path = os.path.join(SRC, src)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _deps_mtime()):
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _deps_mtime(),
+                                                                         os.path.getmtime(os.path.abspath(__file__))):
         return obj
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

@@ -1,41 +1,62 @@
-// Flash-style attention for the encoder (bidirectional, key-padding) and the decoder prefill
-// (causal, left-padded rows, GQA).  O(T) memory: the reference stack materialises the [h,T,T] scores.
+// Flash-style attention for the encoder (bidirectional, key-padding) and the decoder prefill (causal, left-padded rows,
+// GQA).  O(T) memory: the reference stack materialises the [h,T,T] scores.
 //
-// Workgroup = 4 waves = 64 query rows (16 per wave) of one (batch, head); K/V tiles of 64 keys go
-// through LDS (K row-major, swizzled for conflict-free ds_read_b128; V transposed so the PV product
-// reads 8 consecutive keys per lane).  Per wave and tile:
-//   S  = Q K^T        MFMA 16x16x32 f16 : A = Q rows (registers), B = K rows (LDS)
-//   online softmax    rows live on (lane>>4, reg), keys on lane&15 -> 4 xor-shuffles per reduction
-//   O += P V          P (C layout) -> per-wave LDS patch -> A layout; B = V^T rows (LDS)
+// Workgroup = 4 waves = 128 query rows (32 per wave: two 16-query tiles) of one (batch, head); K/V tiles of 64 keys are
+// double-buffered in LDS (global -> registers one tile ahead, written after the tile's compute: one barrier per tile).
+// The products are "swapped" so that a QUERY lives on a lane and the softmax never crosses lanes inside a tile:
+//   S^T = K Q^T      MFMA 16x16x32 f16 : A = 16 keys x 32 dims (LDS, XOR-swizzled rows), B = Q^T (registers).  The result
+//                    lane (query = lane & 15, g = lane >> 4) holds the scores of ITS query for keys 16n + 4g + r.
+//   online softmax   16 scores per lane and tile; the row maximum needs two xor-shuffles (over g), the row sum none until
+//                    the very end; the running rescale factor is a per-lane scalar.
+//   O^T += V^T P^T   the fp16-rounded probabilities ARE the B operand of the next MFMA as they stand (the contraction index
+//                    of a 32-key step is the permutation key(g, e) = 16 (2j + e/4) + 4g + e%4, cdna_hip_programming.md
+//                    "An accumulator tile as the next MFMA's operand"); the A operand V^T[dim][key(g, e)] is read from the
+//                    row-major V tile with the transposing LDS read ds_read_b64_tr_b16 (two per fragment) - no transposing
+//                    store, no probability patch in LDS.
+// Per tile and wave: 32 MFMAs, 8 ds_read_b128 + 16 ds_read_b64_tr (head_dim 64), no LDS writes besides the tile staging.
 #include "common.h"
+#include <type_traits>
 
 namespace opus {
 
-constexpr int QB = 64;   // queries per workgroup
-constexpr int KB = 64;   // keys per tile
-constexpr int VPAD = 8;  // halfs of padding on V^T / P rows (keeps 16-B alignment, spreads banks)
+constexpr int QW = 32;          // queries per wave
+constexpr int QB = 4 * QW;      // queries per workgroup
+constexpr int KB = 64;          // keys per tile
 
-template <int HD>
+template <int HDP>
 __device__ __forceinline__ int kswz(int row, int chunk) {
-    if (HD == 128) return chunk ^ (row & 15);
-    if (HD == 64) return chunk ^ ((row >> 1) & 7);
+    if (HDP == 128) return chunk ^ (row & 15);
+    if (HDP == 64) return chunk ^ ((row >> 1) & 7);
     return chunk;
 }
+// V tile: row-major [key][HD], 16-B chunk c of row r stored at c ^ vswz(r): the 8 consecutive rows that the two 16-lane
+// groups of a half wave read with one ds_read_b64_tr_b16 then fall on 64 distinct banks
+template <int HD>
+__device__ __forceinline__ int vswz(int row) {
+    if (HD == 128) return (row & 7) << 1;            // 256-B rows: every row starts on bank 0
+    if (HD == 64) return ((row >> 1) & 3) << 1;      // 128-B rows: rows r, r + 2 collide
+    if (HD == 32) return ((row >> 2) & 1) << 1;      //  64-B rows: rows r, r + 4 collide
+    return 0;                                        //  32-B rows: 8 rows = one bank row
+}
+
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
 
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     constexpr int HDP = HD < 32 ? 32 : HD;      // QK^T k extent (zero-padded for head_dim 16)
     constexpr int KS = HDP / 32;                // MFMA k-steps for QK^T
-    constexpr int NO = HD / 16;                 // output column tiles
+    constexpr int NO = HD / 16;                 // output dim tiles
     constexpr int CH = HDP / 8;                 // 16-B chunks per K row
-    __shared__ __attribute__((aligned(16))) half_t sK[KB * HDP];
-    __shared__ __attribute__((aligned(16))) half_t sVt[HD * (KB + VPAD)];
-    __shared__ __attribute__((aligned(16))) half_t sP[4 * 16 * (KB + VPAD)];
+    constexpr int VC = HD / 8;                  // 16-B chunks per V row
+    __shared__ __attribute__((aligned(16))) half_t sK[2][KB * HDP];
+    __shared__ __attribute__((aligned(16))) half_t sV[2][KB * HD];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, hk = h / p.group;
-    const int q0 = blockIdx.x * QB;
+    const int q0 = blockIdx.x * QB, qw = q0 + wave * QW;
     const int kstart = p.kstart ? p.kstart[b] : 0;
     const int kend = p.kend ? p.kend[b] : p.T;
 
@@ -43,25 +64,28 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     const half_t *Kb = p.K + (int64_t)b * p.k_sb + (int64_t)hk * HD;
     const half_t *Vb = p.V + (int64_t)b * p.v_sb + (int64_t)hk * HD;
 
-    // Q fragments: A operand rows = this wave's 16 queries
-    h8 qf[KS];
-    {
-        int qr = q0 + wave * 16 + li;
+    // Q^T fragments (B operand): column li = query, k = 32 s + 8 g + e
+    h8 qf[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int qr = qw + 16 * t + li;
         qr = qr < p.T ? qr : p.T - 1;
         const half_t *src = Qb + (int64_t)qr * p.q_st;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int d = 32 * s + 8 * g;
-            if (d < HD) qf[s] = *reinterpret_cast<const h8 *>(src + d);
-            else qf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            qf[t][s] = d < HD ? *reinterpret_cast<const h8 *>(src + d) : h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    f4 o[NO];
+    f4 o[2][NO];
+    float mrow[2], lrow[2];
 #pragma unroll
-    for (int n = 0; n < NO; ++n) o[n] = f4{0.f, 0.f, 0.f, 0.f};
-    float mrow[4], lrow[4];
+    for (int t = 0; t < 2; ++t) {
+        mrow[t] = -INFINITY;
+        lrow[t] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+        for (int n = 0; n < NO; ++n) o[t][n] = f4{0.f, 0.f, 0.f, 0.f};
+    }
 
     int k_lo = kstart / KB * KB;
     int k_hi = kend;
@@ -69,13 +93,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         const int last_q = (q0 + QB - 1 < p.T - 1 ? q0 + QB - 1 : p.T - 1);
         k_hi = k_hi < last_q + 1 ? k_hi : last_q + 1;
     }
-    half_t *myP = sP + wave * 16 * (KB + VPAD);
     const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
+    const bool wave_live = qw < p.T;                  // waves past the last query only help with the tile staging
 
-    // K/V tiles are double-buffered through registers: the global loads of tile t+1 are issued right after tile t has
-    // been copied into LDS, so their latency runs under the MFMA / softmax work of tile t.
+    // K/V tiles: global -> registers one tile ahead of the LDS copy
     constexpr int KL = KB * CH / 256;            // 16-B pieces of K per thread and tile
-    constexpr int VN = KB * (HD / 8);            // 16-B pieces of V per tile (128 for head_dim 16: half the threads idle)
+    constexpr int VN = KB * VC;                  // 16-B pieces of V per tile (128 for head_dim 16: half the threads idle)
     constexpr int VL = VN >= 256 ? VN / 256 : 1;
     static_assert(KL >= 1, "tile too small for 256 threads");
     h8 kreg[KL], vreg[VL];
@@ -90,138 +113,148 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         }
 #pragma unroll
         for (int u = 0; u < VL; ++u) {
-            const int i = tid + 256 * u, r = i / (HD / 8), c = i % (HD / 8);
+            const int i = tid + 256 * u, r = i / VC, c = i % VC;
             int kr = kt + r;
             kr = kr < p.T ? kr : p.T - 1;
             vreg[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
             if (i < VN) vreg[u] = *reinterpret_cast<const h8 *>(Vb + (int64_t)kr * p.v_st + c * 8);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < KL; ++u) {
             const int i = tid + 256 * u, r = i / CH, c = i % CH;
-            *reinterpret_cast<h8 *>(sK + r * HDP + kswz<HDP>(r, c) * 8) = kreg[u];
+            *reinterpret_cast<h8 *>(&sK[buf][r * HDP + kswz<HDP>(r, c) * 8]) = kreg[u];
         }
-        // V^T: lanes (r, c) and (r^1, c) sit HD/8 lanes apart; they swap halves of their 8 dims so that each writes
-        // four {key r&~1, key r|1} pairs as 32-bit words instead of eight 16-bit ones
 #pragma unroll
         for (int u = 0; u < VL; ++u) {
-            const int i = tid + 256 * u, r = i / (HD / 8), c = i % (HD / 8);
-            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-            const u4v mine = __builtin_bit_cast(u4v, vreg[u]);
-            const bool odd = r & 1;
-            // send the half the partner writes, keep the half this lane writes (even rows: dims 0..3, odd rows: 4..7)
-            const unsigned s0 = odd ? mine[0] : mine[2], s1 = odd ? mine[1] : mine[3];
-            const unsigned k0 = odd ? mine[2] : mine[0], k1 = odd ? mine[3] : mine[1];
-            const unsigned o0 = __shfl_xor(s0, HD / 8, 64), o1 = __shfl_xor(s1, HD / 8, 64);
-            // k0/k1: this lane's key, two dims per word; o0/o1: the partner key, same dims
-            const unsigned lo0 = odd ? o0 : k0, hi0 = odd ? k0 : o0;     // even key in the low half of each output word
-            const unsigned lo1 = odd ? o1 : k1, hi1 = odd ? k1 : o1;
-            const int d0 = c * 8 + (odd ? 4 : 0), re = r & ~1;
-            unsigned *dst = reinterpret_cast<unsigned *>(sVt);
-            constexpr int RW = (KB + VPAD) / 2;                           // words per V^T row
-            if (i >= VN) continue;
-            dst[(d0 + 0) * RW + (re >> 1)] = (lo0 & 0xffffu) | (hi0 << 16);
-            dst[(d0 + 1) * RW + (re >> 1)] = (lo0 >> 16) | (hi0 & 0xffff0000u);
-            dst[(d0 + 2) * RW + (re >> 1)] = (lo1 & 0xffffu) | (hi1 << 16);
-            dst[(d0 + 3) * RW + (re >> 1)] = (lo1 >> 16) | (hi1 & 0xffff0000u);
+            const int i = tid + 256 * u, r = i / VC, c = i % VC;
+            if (i < VN) *reinterpret_cast<h8 *>(&sV[buf][r * HD + (c ^ vswz<HD>(r)) * 8]) = vreg[u];
         }
     };
 
-    if (k_lo < k_hi) load_tile(k_lo);
-    for (int kt = k_lo; kt < k_hi; kt += KB) {
-        __syncthreads();   // previous tile fully consumed
-        store_tile();
-        if (kt + KB < k_hi) load_tile(kt + KB);
-        __syncthreads();
-
-        // ---- S = Q K^T : 4 column tiles of 16 keys ----
-        f4 s[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            s[n] = f4{0.f, 0.f, 0.f, 0.f};
-            const int r = 16 * n + li;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const h8 kf = *reinterpret_cast<const h8 *>(sK + r * HDP + kswz<HDP>(r, 4 * ks + g) * 8);
-                s[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[ks], kf, s[n], 0, 0, 0);
-            }
-        }
-        // ---- mask + online softmax (row = 4g + r, key = kt + 16n + li) ----
-        // interior: every key of the tile is visible to every query row of this workgroup (block-uniform)
-        const bool interior = kt >= kstart && kt + KB <= kend && (!CAUSAL || kt + KB - 1 <= q0);
-        float alpha[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + wave * 16 + 4 * g + r;
-            float mx = -INFINITY;
+    if (k_lo < k_hi) {
+        load_tile(k_lo);
+        store_tile(0);
+        if (k_lo + KB < k_hi) load_tile(k_lo + KB);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int kt = k_lo; kt < k_hi; kt += KB, buf ^= 1) {
+        if (wave_live) {
+            const half_t *tK = sK[buf], *tV = sV[buf];
+            // ---- S^T = K Q^T : 4 key subtiles x 2 query tiles ----
+            f4 s[2][4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                float v = s[n][r] * sc;
-                if (!interior) {                                     // tiles that touch a padding / causal boundary
-                    const int kj = kt + 16 * n + li;
-                    bool vis = kj >= kstart && kj < kend;
-                    if (CAUSAL) vis = vis && kj <= qi;
-                    v = vis ? v : -INFINITY;
+                const int r = 16 * n + li;
+                h8 kf[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const h8 *>(tK + r * HDP + kswz<HDP>(r, 4 * ks + g) * 8);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s[t][n] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) s[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[ks], qf[t][ks], s[t][n], 0, 0, 0);
                 }
-                s[n][r] = v;
-                mx = fmaxf(mx, v);
             }
+            // ---- mask + online softmax: lane (li, g) owns query qw + 16 t + li, keys kt + 16 n + 4 g + r ----
+            // interior: every key of the tile is visible to every query row of this wave (wave-uniform): no masking code
+            const bool interior = kt >= kstart && kt + KB <= kend && (!CAUSAL || kt + KB - 1 <= qw);
+            h8 pf[2][2];
+            auto softmax = [&](auto masked_tag) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-            const float mnew = fmaxf(mrow[r], mx);
-            const float msafe = mnew == -INFINITY ? 0.f : mnew;
-            alpha[r] = exp2f(mrow[r] - msafe);          // 0 when mrow = -inf
-            float rs = 0.f;
+                for (int t = 0; t < 2; ++t) {
+                    if (MASKED) {                                        // tiles that touch a padding / causal boundary
+                        const int qi = qw + 16 * t + li;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const float e = exp2f(s[n][r] - msafe);
-                s[n][r] = e;
-                rs += e;
-            }
+                        for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off, 64);
-            lrow[r] = lrow[r] * alpha[r] + rs;
-            mrow[r] = mnew;
+                            for (int r = 0; r < 4; ++r) {
+                                const int kj = kt + 16 * n + 4 * g + r;
+                                bool vis = kj >= kstart && kj < kend;
+                                if (CAUSAL) vis = vis && kj <= qi;
+                                s[t][n][r] = vis ? s[t][n][r] : -INFINITY;
+                            }
+                    }
+                    // row maximum of the raw scores (the scale is positive): 16 in-lane values, then the four lane groups
+                    float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+#pragma unroll
+                    for (int n = 1; n < 4; ++n) mx = fmaxf(fmaxf(mx, fmaxf(s[t][n][0], s[t][n][1])), fmaxf(s[t][n][2], s[t][n][3]));
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float mnew = fmaxf(mrow[t], mx);
+                    const float msafe = MASKED ? (mnew == -INFINITY ? 0.f : mnew) : mnew;   // interior tiles: finite
+                    const float msc = msafe * sc;
+                    if (!__all(mnew == mrow[t])) {                       // (wave-uniform) some row's maximum grew: rescale
+                        const float alpha = __builtin_amdgcn_exp2f((mrow[t] - msafe) * sc);   // 0 when mrow = -inf
+                        lrow[t] *= alpha;
+#pragma unroll
+                        for (int n = 0; n < NO; ++n) o[t][n] *= alpha;
+                        mrow[t] = mnew;
+                    }
+                    float rs = 0.f;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][n][r], sc, -msc));
+                            s[t][n][r] = e;
+                            rs += e;
+                        }
+                    lrow[t] += rs;                                       // this lane's keys only: summed over g at the end
+                    // P^T fragments: 32-key step j = subtiles 2j, 2j+1; element e -> key 16 (2j + e/4) + 4g + e%4
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        pf[t][j] = h8{(half_t)s[t][2 * j][0], (half_t)s[t][2 * j][1], (half_t)s[t][2 * j][2], (half_t)s[t][2 * j][3],
+                                      (half_t)s[t][2 * j + 1][0], (half_t)s[t][2 * j + 1][1], (half_t)s[t][2 * j + 1][2], (half_t)s[t][2 * j + 1][3]};
+                }
+            };
+            if (interior) softmax(std::false_type{});
+            else softmax(std::true_type{});
+            // ---- O^T += V^T P^T : A = V^T[dim 16 n + li][key(g, e)] by two transposing reads per fragment ----
+            // ds_read_b64_tr_b16: lane i of a 16-lane group supplies the address of row (i >> 2), columns 4 (i & 3) .. + 3 of
+            // a 4-row x 16-column block and receives column i of the four rows
+#pragma unroll
+            for (int n = 0; n < NO; ++n)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r0 = 16 * (2 * j) + 4 * g + (li >> 2), r1 = r0 + 16;
+                    const int cc = 2 * n + ((li & 3) >> 1), off = (li & 1) * 4;
+                    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4v *)(tV + r0 * HD + (cc ^ vswz<HD>(r0)) * 8 + off));
+                    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4v *)(tV + r1 * HD + (cc ^ vswz<HD>(r1)) * 8 + off));
+                    const s8v both = s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const h8 vf = __builtin_bit_cast(h8, both);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][j], o[t][n], 0, 0, 0);
+                }
         }
-#pragma unroll
-        for (int n = 0; n < NO; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[n][r] *= alpha[r];
-        // ---- P: C layout -> LDS patch [16 q][64 keys] -> A layout ----
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) myP[(4 * g + r) * (KB + VPAD) + 16 * n + li] = (half_t)s[n][r];
-        // same-wave LDS round trip: the wave's own ds_write -> ds_read ordering is kept by hardware
-        // (in-order LDS queue); the compiler fence stops reordering of the accesses.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        h8 pf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            pf[ks] = *reinterpret_cast<const h8 *>(myP + li * (KB + VPAD) + 32 * ks + 8 * g);
-        // ---- O += P V ----
-#pragma unroll
-        for (int n = 0; n < NO; ++n)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const h8 vf = *reinterpret_cast<const h8 *>(sVt + (16 * n + li) * (KB + VPAD) + 32 * ks + 8 * g);
-                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[ks], vf, o[n], 0, 0, 0);
-            }
+        // next tile: registers -> the other LDS buffer (its last readers passed the previous barrier), then fetch the one after
+        if (kt + KB < k_hi) {
+            store_tile(buf ^ 1);
+            if (kt + 2 * KB < k_hi) load_tile(kt + 2 * KB);
+        }
+        __syncthreads();
     }
 
-    // ---- epilogue: O / l -> fp16 [b, t, h*HD + d] ----
+    // ---- epilogue: O / l -> fp16 [b, t, h*HD + d]; lane (li, g) holds dims 16 n + 4 g + r of query li ----
+    if (!wave_live) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wave * 16 + 4 * g + r;
+    for (int t = 0; t < 2; ++t) {
+        float l = lrow[t];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int qi = qw + 16 * t + li;
         if (qi >= p.T) continue;
-        const float inv = lrow[r] > 0.f ? 1.0f / lrow[r] : 0.f;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
         half_t *dst = p.O + (int64_t)b * p.o_sb + (int64_t)qi * p.o_st + (int64_t)h * HD;
 #pragma unroll
-        for (int n = 0; n < NO; ++n) dst[16 * n + li] = (half_t)(o[n][r] * inv);
+        for (int n = 0; n < NO; ++n)
+            *reinterpret_cast<h4 *>(dst + 16 * n + 4 * g) =
+                h4{(half_t)(o[t][n][0] * inv), (half_t)(o[t][n][1] * inv), (half_t)(o[t][n][2] * inv), (half_t)(o[t][n][3] * inv)};
     }
 }
 
@@ -235,6 +268,9 @@ static hipError_t launch_hd(const AttnParams &p, hipStream_t s) {
 
 hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s) {
     if (p.T <= 0 || p.B <= 0) return hipErrorInvalidValue;
+    // the 8-byte output stores and 16-byte operand loads need these alignments (every caller of the path satisfies them)
+    if ((p.o_st & 3) || (p.o_sb & 3) || (p.q_st & 7) || (p.k_st & 7) || (p.v_st & 7) || (p.q_sb & 7) || (p.k_sb & 7) || (p.v_sb & 7))
+        return hipErrorInvalidValue;
     switch (p.head_dim) {
         case 16: return launch_hd<16>(p, s);
         case 32: return launch_hd<32>(p, s);

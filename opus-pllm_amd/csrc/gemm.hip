@@ -1486,7 +1486,8 @@ static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
     const int blocks = cdiv((p.N + 15) >> 4, 8), chunks = p.K / 64;
     int ks = 1;
     if (p.ws && blocks < 200) {                                      // few column groups: split K over workgroups
-        ks = cdiv(256, blocks);
+        // one workgroup per CU (128 KB of LDS each): blocks x ks must not spill into a second round of 256
+        ks = 256 / blocks;
         ks = ks > 8 ? 8 : ks;
         if (ks > chunks / 8) ks = chunks / 8;
         while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;

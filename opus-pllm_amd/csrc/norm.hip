@@ -7,7 +7,7 @@
 
 namespace opus {
 
-constexpr int NV = 20;  // float4 per lane -> rows up to 64*4*20 = 5120 columns
+constexpr int NV_MAX = 20;  // float4 per lane -> rows up to 64*4*20 = 5120 columns
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -15,7 +15,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <int MODE>  // 0 layernorm, 1 rmsnorm, 2 l2norm
+// NV = float4 per lane: instantiated for 5 (D <= 1280: ESM2-650M), 10 (<= 2560: ESM2-3B), 16 (<= 4096) and 20 (<= 5120), so the
+// row lives in exactly the registers it needs (occupancy) and no predicated-off iterations are issued
+template <int MODE, int NV>  // MODE: 0 layernorm, 1 rmsnorm, 2 l2norm
 __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ b, float eps, int64_t rows, int D,
                                                       half_t *__restrict__ out_h, float *__restrict__ out_f) {
@@ -75,23 +77,26 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
     }
 }
 
+template <int MODE>
+static hipError_t launch_rownorm(const float *x, const float *w, const float *b, float eps, int64_t rows, int D, half_t *out_h,
+                                 float *out_f, hipStream_t s) {
+    if (D > NV_MAX * 256 || (D & 3)) return hipErrorInvalidValue;
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    if (D <= 5 * 256) OPUS_LAUNCH(KC_NORM, (rownorm_kernel<MODE, 5>), grid, block, 0, s, x, w, b, eps, rows, D, out_h, out_f);
+    else if (D <= 10 * 256) OPUS_LAUNCH(KC_NORM, (rownorm_kernel<MODE, 10>), grid, block, 0, s, x, w, b, eps, rows, D, out_h, out_f);
+    else if (D <= 16 * 256) OPUS_LAUNCH(KC_NORM, (rownorm_kernel<MODE, 16>), grid, block, 0, s, x, w, b, eps, rows, D, out_h, out_f);
+    else OPUS_LAUNCH(KC_NORM, (rownorm_kernel<MODE, 20>), grid, block, 0, s, x, w, b, eps, rows, D, out_h, out_f);
+    return hipGetLastError();
+}
 hipError_t launch_layernorm(const float *x, const float *w, const float *b, float eps, int64_t rows, int D,
                             half_t *out_h, float *out_f, hipStream_t s) {
-    if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
-    OPUS_LAUNCH(KC_NORM, rownorm_kernel<0>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, eps, rows, D, out_h, out_f);
-    return hipGetLastError();
+    return launch_rownorm<0>(x, w, b, eps, rows, D, out_h, out_f, s);
 }
 hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t rows, int D, half_t *out, hipStream_t s) {
-    if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
-    OPUS_LAUNCH(KC_NORM, rownorm_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, nullptr, eps, rows, D, out,
-                       (float *)nullptr);
-    return hipGetLastError();
+    return launch_rownorm<1>(x, w, nullptr, eps, rows, D, out, nullptr, s);
 }
 hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s) {
-    if (D > NV * 256 || (D & 3)) return hipErrorInvalidValue;
-    OPUS_LAUNCH(KC_NORM, rownorm_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, nullptr, nullptr, 0.f, rows, D,
-                       out, (float *)nullptr);
-    return hipGetLastError();
+    return launch_rownorm<2>(x, nullptr, nullptr, 0.f, rows, D, out, nullptr, s);
 }
 
 // fp32 -> fp16 cast (the identity protein projector of opus_arch.py:70-80 hands the pooled fp32 embedding straight to the

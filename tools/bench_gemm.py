@@ -21,16 +21,18 @@ lib = _cabi.lib()
 def bench(name, M, N, K, epi, norm, data="rand", iters=None):
     bytes_ = 2 * N * K
     nbuf = max(2, min(40, int(6e9 // bytes_)))
+    if os.environ.get("BENCH_NBUF"):                # 1 = the same weights every launch (Infinity-Cache-warm when they fit)
+        nbuf = int(os.environ["BENCH_NBUF"])
     if data == "rand":
         bufs = [(torch.randn(N * K // 2, device=dev) * 0.02).half().view(-1) for _ in range(2)]
-        bufs = [torch.cat([bufs[i % 2], bufs[(i + 1) % 2]]).clone() for i in range(nbuf)]
+        bufs = [torch.cat([bufs[i % 2], bufs[(i + 1) % 2]]).clone() for i in range(max(nbuf, 1))]
     else:
         bufs = [torch.full((N * K,), 1.0, dtype=torch.float16, device=dev) for _ in range(nbuf)]
     nout = N // 2 if epi == 2 else N
     A16 = torch.randn(M, K, device=dev).half()
     A32 = torch.randn(M, K, device=dev)
     out = torch.empty(M, nout, dtype=torch.float16, device=dev)
-    iters = iters or nbuf * 3
+    iters = iters or max(nbuf * 3, 30)
 
     def run(i):
         w = bufs[i % nbuf]
