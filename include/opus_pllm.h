@@ -112,7 +112,7 @@ int opus_esm2_last_hidden(opus_ctx *ctx, float *d_out, int32_t B, int32_t T, voi
  * fp16 [B, n_prot_tokens, dec_dim].  d_proj_out (optional, may be NULL) receives the P1 output
  * fp16 [B, proj_dim].  B is NOT limited by max_batch: the batched stage of the two-stage pipeline (SURVEY 8f N3,
  * opus_arch.py:151-161 + scripts/generate_esm_embedding.py) projects whole dataset shards at M >= 512, in chunks of
- * max(max_batch, 1024) rows.  has_protein_projector = 0 is the identity module of opus_arch.py:70-80: P1 is a cast. */
+ * max(max_batch, 4096) rows.  has_protein_projector = 0 is the identity module of opus_arch.py:70-80: P1 is a cast. */
 int opus_projector_forward(opus_ctx *ctx, const float *d_pooled, int32_t B, void *d_out, void *d_proj_out,
                            void *stream);
 /* Row P1 alone: encode_projector_embedding (opus_arch.py:115-121): fp32 [B,enc_dim] -> fp16 [B,proj_dim]. */

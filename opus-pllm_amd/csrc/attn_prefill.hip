@@ -55,8 +55,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / p.group;
-    const int q0 = blockIdx.x * QB, qw = q0 + wave * QW;
+    // Workgroup ids are dealt round-robin over the 8 XCDs: ids that are equal mod 8 share an L2.  All query blocks of one
+    // (batch, head) - which stream the same K / V - therefore take ids of one residue class: K / V come from HBM / the
+    // Infinity Cache once per (batch, head) instead of once per query block.  (Placement is a speed matter only.)
+    const int nqb = (p.T + QB - 1) / QB;
+    const int id = blockIdx.x, slot = id >> 3;
+    const int bh = (slot / nqb) * 8 + (id & 7);
+    if (bh >= p.B * p.heads) return;
+    const int b = bh / p.heads, h = bh % p.heads, hk = h / p.group;
+    const int q0 = (slot % nqb) * QB, qw = q0 + wave * QW;
     const int kstart = p.kstart ? p.kstart[b] : 0;
     const int kend = p.kend ? p.kend[b] : p.T;
 
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                                       (half_t)s[t][2 * j + 1][0], (half_t)s[t][2 * j + 1][1], (half_t)s[t][2 * j + 1][2], (half_t)s[t][2 * j + 1][3]};
                 }
             };
-            if (interior) softmax(std::false_type{});
+            if (__builtin_expect(interior, 1)) softmax(std::false_type{});
             else softmax(std::true_type{});
             // ---- O^T += V^T P^T : A = V^T[dim 16 n + li][key(g, e)] by two transposing reads per fragment ----
             // ds_read_b64_tr_b16: lane i of a 16-lane group supplies the address of row (i >> 2), columns 4 (i & 3) .. + 3 of
@@ -260,7 +267,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 
 template <int HD>
 static hipError_t launch_hd(const AttnParams &p, hipStream_t s) {
-    dim3 grid(cdiv(p.T, QB), p.heads, p.B);
+    const int nqb = cdiv(p.T, QB);
+    dim3 grid(((p.B * p.heads + 7) / 8) * 8 * nqb);
     if (p.causal) OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, true>), grid, dim3(256), 0, s, p);
     else OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, false>), grid, dim3(256), 0, s, p);
     return hipGetLastError();

@@ -930,26 +930,46 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_
 // least 3 phases later; its slot was last read >= 2 phases (4 barriers) before the request.  RAW: the reader passes a
 // barrier after every wave's counted vmcnt (one phase later, both wave-rows); WAR: see above.
 constexpr int PP_DIST = 6;   // half-tiles requested ahead (4..6)
+
+// tile id -> (tile row, tile column): GM tile-rows are walked column by column, so the ~32 tiles an XCD works on at one time
+// form a compact 2-D patch sharing A rows and weight panels in that XCD's L2
+__host__ __device__ __forceinline__ void pp_tile_coords(int id, int tiles_m, int tiles_n, int &tm, int &tn) {
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int grp = id / per_group, rem_id = id - grp * per_group;
+    const int rows_here = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;
+    tm = grp * GM + rem_id % rows_here;
+    tn = rem_id / rows_here;
+}
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m, int tiles_n, int full_tiles, int tail_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HT = 16384;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, li = lane & 15;
-    int bid = blockIdx.x;
-    {   // XCD-aware order, as the ring kernel
-        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    // Tail split.  The first `full_tiles` workgroups (a whole number of rounds of 256) each own one tile over the full K; the
+    // tiles left over - a last, partly filled round that would cost a full tile time - are cut into `tail_split` k-parts each,
+    // so that the round is as many workgroups but 1 / tail_split as long; the parts leave raw fp32 tiles in the workspace
+    // for pp_tail_reduce_kernel (fixed summation order: bitwise reproducible).
+    int bid = blockIdx.x, kpart = 0;
+    const bool partial = bid >= full_tiles;
+    if (!partial) {   // XCD-aware order, as the ring kernel
+        const int nwg = full_tiles, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
         bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    } else {
+        const int j = bid - full_tiles;
+        bid = full_tiles + j / tail_split;
+        kpart = j % tail_split;
     }
-    constexpr int GM = 8;
-    const int per_group = GM * tiles_n;
-    const int grp = bid / per_group, rem_id = bid - grp * per_group;
-    const int rows_here = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;
-    const int tm = grp * GM + rem_id % rows_here, tn = rem_id / rows_here;
+    int tm, tn;
+    pp_tile_coords(bid, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
-    const int KT = p.K >> 6, NH = 4 * KT;
+    const int KT_all = p.K >> 6;
+    const int kt0 = partial ? (int)((int64_t)KT_all * kpart / tail_split) : 0;
+    const int kt1 = partial ? (int)((int64_t)KT_all * (kpart + 1) / tail_split) : KT_all;
+    const int KT = kt1 - kt0, NH = 4 * KT;
     const int npanels = (p.N + 15) >> 4;
 
     typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -965,14 +985,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         for (int rh = 0; rh < 2; ++rh) {
             int row = m0 + (lr >> 6) * 128 + rh * 64 + (lr & 63);
             row = row < p.M ? row : p.M - 1;
-            srcA[j][rh] = p.A + (int64_t)row * p.lda + chunk * 8;
+            srcA[j][rh] = p.A + (int64_t)row * p.lda + chunk * 8 + (int64_t)kt0 * 64;
         }
         const int pi = q >> 1, s = q & 1;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             int pn = (n0 >> 4) + (pi >> 1) * 4 + ch * 2 + (pi & 1);
             pn = pn < npanels ? pn : npanels - 1;
-            srcB[j][ch] = p.W + ((int64_t)pn * KT) * 1024 + s * 512 + lane * 8;
+            srcB[j][ch] = p.W + ((int64_t)pn * KT_all + kt0) * 1024 + s * 512 + lane * 8;
         }
     }
     auto issue_half = [&](int hq) {
@@ -1087,6 +1107,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                        // every wave executes the same number of barriers
 
+    if (partial) {   // raw fp32 tile [256][256] of this k-part (rows / columns beyond M / N hold clamped-row products: never read)
+        float *slab = p.ws + (((int64_t)(bid - full_tiles) * tail_split + kpart) << 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wr * 128 + i * 16 + li;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4 *>(slab + r * 256 + wc * 64 + j * 16 + 4 * g) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        return;
+    }
     // ---- epilogue ----
     // The accumulators hold 4 consecutive columns of 16 different rows per lane group: stored directly, a wave-wide
     // store touches 16 rows x 32-B pieces.  The LDS is idle now, so each wave turns its 16-row x 64-column slabs
@@ -1186,12 +1217,105 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     }
 }
 
+// Combines the k-parts of the tail tiles of gemm_pp_kernel.  Workgroup = 32 rows of one tile (8 per wave); a lane owns 4
+// consecutive GEMM columns, so every load of a slab row is one fully coalesced 1-KB wave access and the epilogue moves 16-B
+// (fp32) / 8-B (fp16) pieces.  Parts are summed in a fixed order, then the epilogue of the GEMM is applied.  With
+// EPI_SILU_GU16 the gate columns (col % 32 < 16) fetch their up values from the lane 4 above.
+template <int EPI>
+__global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int tiles_m, int tiles_n, int full_tiles, int tail_split) {
+    int tm, tn;
+    pp_tile_coords(full_tiles + blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = 4 * lane, n = tn * 256 + col;
+    const float *base = p.ws + ((int64_t)blockIdx.x * tail_split << 16) + col;
+    f4 bias4 = f4{0.f, 0.f, 0.f, 0.f}, bias_up = f4{0.f, 0.f, 0.f, 0.f};
+    const bool gate_lane = (col & 31) < 16;
+    if (p.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (n + c < p.N) bias4[c] = p.bias[n + c];
+            if (EPI == EPI_SILU_GU16 && gate_lane && n + 16 + c < p.N) bias_up[c] = p.bias[n + 16 + c];
+        }
+    }
+    constexpr int RW = 8;                                            // rows per wave
+    f4 v[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) v[i] = f4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = blockIdx.y * 32 + wave * RW;
+    for (int k = 0; k < tail_split; ++k) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const float4 t = *reinterpret_cast<const float4 *>(base + ((int64_t)k << 16) + (r0 + i) * 256);
+            v[i][0] += t.x; v[i][1] += t.y; v[i][2] += t.z; v[i][3] += t.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int m = tm * 256 + r0 + i;
+        f4 x = v[i];
+        int no = n;
+        bool live = m < p.M;                                          // (the shuffle below needs every lane)
+        if (EPI == EPI_SILU_GU16) {
+            f4 up;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) up[c] = __shfl_down(x[c], 4, 64);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = silu(x[c] + bias4[c]) * (up[c] + bias_up[c]);
+            no = ((n >> 5) << 4) + (n & 15);
+            live = live && gate_lane && n + 16 < p.N;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                x[c] += bias4[c];
+                if (EPI == EPI_GELU) x[c] = gelu_erf(x[c]);
+            }
+            live = live && n < p.N;
+        }
+        if (!live) continue;
+        const int nlim = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
+        if (no + 3 < nlim && ((p.ldc | p.ldr) & 3) == 0) {
+            if (p.residual) {
+                const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + no);
+                x[0] += rr.x; x[1] += rr.y; x[2] += rr.z; x[3] += rr.w;
+            }
+            if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + no) = make_float4(x[0], x[1], x[2], x[3]);
+            else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + no) = h4{(half_t)x[0], (half_t)x[1], (half_t)x[2], (half_t)x[3]};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (no + c >= nlim) continue;
+                float y = x[c];
+                if (p.residual) y += p.residual[(int64_t)m * p.ldr + no + c];
+                if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no + c] = y;
+                else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no + c] = (half_t)y;
+            }
+        }
+    }
+}
+
 template <int EPI>
 static hipError_t launch_pp(const GemmParams &p, hipStream_t s) {
     const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_pp_kernel<EPI>), 8 * 16384);
     if (ea != hipSuccess) return ea;
-    OPUS_LAUNCH(KC_PP, (gemm_pp_kernel<EPI>), dim3(bm * bn), dim3(512), 8 * 16384, s, p, bm, bn);
+    // tail split: when the last round of 256 workgroups would be at most half full, its tiles are cut into k-parts that fill it
+    const int T = bm * bn, KT = p.K >> 6;
+    int full = T, split = 1;
+    static const bool no_tail = getenv("OPUS_NO_PP_TAIL") != nullptr;   // A/B aid
+    const int R = T % 256;
+    if (!no_tail && p.ws && T > 256 && R > 0 && R <= 128) {
+        int sp = 256 / R;
+        sp = sp > 8 ? 8 : sp;
+        if (sp > KT / 4) sp = KT / 4;                                 // at least 4 k-tiles per part (pipeline prologue)
+        while (sp > 1 && ((int64_t)R * sp << 18) > p.ws_bytes) --sp;
+        if (sp > 1) { full = T - R; split = sp; }
+    }
+    const int tail = T - full;
+    OPUS_LAUNCH(KC_PP, (gemm_pp_kernel<EPI>), dim3(full + tail * split), dim3(512), 8 * 16384, s, p, bm, bn, full, split);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || split == 1) return e;
+    if (tl_launch_ev) tl_launch_ev->aux_bytes = ((double)tail * split * 65536 * 4) + (double)tail * 65536 * (p.out_f32 ? 4 : 2);
+    OPUS_LAUNCH(KC_REDUCE, (pp_tail_reduce_kernel<EPI>), dim3(tail, 8), dim3(256), 0, s, p, bm, bn, full, split);
     return hipGetLastError();
 }
 

@@ -202,7 +202,7 @@ class OpusLlamaForCausalLM:
         """The batched projector stage of the two-stage pipeline: pooled ESM-2 embeddings of a whole dataset
         shard fp32 [N, enc_dim] (the `input_embed` field written by generate_esm_embedding.py, consumed by the reference at
         opus_arch.py:151-161) -> protein tokens fp16 [N, n_prot_tokens, hidden] in ONE call, i.e. the modality projectors run
-        at M = N (>= 512 for any real dataset: MFMA-bound GEMMs, processed in chunks of max(max_batch, 1024) rows) instead of
+        at M = N (>= 512 for any real dataset: MFMA-bound GEMMs, processed in chunks of max(max_batch, 4096) rows) instead of
         re-streaming their 2.5 GB of weights for every batch of 8.  Feed slices of the result to generate(protein_tokens=...)."""
         x = pooled.to(self.device, torch.float32).contiguous()
         N = x.shape[0]

@@ -91,6 +91,9 @@ def test_synthetic_fill_matches_numpy_twin(dev):
     (24, 16384, 1024, 0, 0, False), (32, 16416, 4096, 2, 0, False), (64, 20480, 1088, 1, 0, False), (90, 16384, 576, 2, 0, False),
     # >= 192 tiles of 256 x 256: the ping-pong 256 x 256 x 64 kernel (ragged M/N; 5, 1, 2, 10 K-tiles: prologue / tail paths)
     (4100, 3000, 320, 1, 0, False), (3000, 4100, 64, 0, 1, True), (2600, 5120, 128, 2, 0, False), (3900, 3328, 640, 0, 0, False),
+    # more than 256 tiles with a last round at most half full: its tiles are cut into k-parts (tail split) and combined by
+    # pp_tail_reduce_kernel - every epilogue / output type, ragged M and N inside the tail tiles
+    (1300, 11100, 1280, 0, 0, False), (1280, 13312, 1024, 2, 0, False), (2304, 7424, 1280, 1, 0, False), (4608, 4608, 512, 0, 1, True),
 ])
 def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
     """Both GEMM kernels (skinny M<=64, tile M>64), every epilogue, ragged M/N, vs fp64 on fp16 operands."""
@@ -274,13 +277,13 @@ def test_projector_variants_golden(dev, gold, tag, kw):
 
 def test_projector_rows_beyond_max_batch(micro, dev):
     """The batched projector stage of the two-stage pipeline: B is not bounded by max_batch; rows are
-    processed in chunks of max(max_batch, 1024) and every row equals the same row projected alone."""
+    processed in chunks of max(max_batch, 4096) and every row equals the same row projected alone."""
     cfg, model, W = micro
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(2500, cfg.enc_dim, generator=g) * 2.0
+    x = torch.randn(9000, cfg.enc_dim, generator=g) * 2.0
     z = model.switch_projector_embedding(model.encode_projector_embedding(x))
-    assert z.shape == (2500, cfg.n_prot_tokens, cfg.dec_dim)
-    for i in (0, 1023, 1024, 2047, 2499):
+    assert z.shape == (9000, cfg.n_prot_tokens, cfg.dec_dim)
+    for i in (0, 4095, 4096, 8191, 8192, 8999):
         zi = model.switch_projector_embedding(model.encode_projector_embedding(x[i:i + 1]))
         assert rel_l2(zi[0].float(), z[i].float()) < 2e-3, i
     import oracle

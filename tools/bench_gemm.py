@@ -93,6 +93,11 @@ if __name__ == "__main__":
         bench_tile("square 4096", 4096, 4096, 4096, 0)
         bench_tile("square 8192", 8192, 8192, 8192, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "proj":
+        for M in (256, 512, 768, 1024, 2048, 4096):
+            bench_tile("projector sw1 gelu", M, 32768, 5120, 1, iters=10)
+            bench_tile("projector sw2", M, 32768, 32768, 0, iters=6)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "m96":
         for M in (96, 128, 514, 1028, 2056, 4112, 8224):
             if M <= 128:
