@@ -1141,8 +1141,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         }
         return;
     }
-    float *patch = reinterpret_cast<float *>(smem + wave * 16384);     // [16 rows][NO + 4] fp32
-    constexpr int PS = NO + 4;
+    // Patch image.  64 output columns: rows of 64 floats, the 16-B slot q of row r kept at q ^ (r & 15) - conflict-free both
+    // for the 8-lane groups of the ds_write_b128 (8 rows, one slot column) and for the 16-lane groups of the ds_read_b128
+    // (lanes 0-3 / 12-15 of one row with lanes 4-11 of the next).  32 output columns (gate / up): rows padded by one slot;
+    // the row-segment reads then collide 2-way on one lane of 16 (one extra LDS cycle per read: this padding, on both
+    // widths, was the SQ_LDS_BANK_CONFLICT count of round 1's projector profile - 1.3 M cycles in 5 launches, 0.05 %).
+    float *patch = reinterpret_cast<float *>(smem + wave * 16384);
+    constexpr bool XSW = NO == 64;
+    constexpr int PS = XSW ? NO : NO + 4;
+    auto pidx = [&](int r, int c) { return XSW ? r * PS + ((((c >> 2) ^ (r & 15)) << 2) | (c & 3)) : r * PS + c; };
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         // 1. bias / activation in registers, 4 columns per lane -> patch[li][...]
@@ -1157,7 +1164,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                     if (p.bias) { gate += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
                     v[r] = silu(gate) * up;
                 }
-                *reinterpret_cast<f4 *>(patch + li * PS + jj * 16 + 4 * g) = v;
+                *reinterpret_cast<f4 *>(patch + pidx(li, jj * 16 + 4 * g)) = v;
             }
         } else {
 #pragma unroll
@@ -1169,7 +1176,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                     if (p.bias) v[r] += p.bias[nb + r];
                     if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
                 }
-                *reinterpret_cast<f4 *>(patch + li * PS + j * 16 + 4 * g) = v;
+                *reinterpret_cast<f4 *>(patch + pidx(li, j * 16 + 4 * g)) = v;
             }
         }
         // same-wave LDS round trip (in-order LDS queue); the fences keep the compiler from reordering across it
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
             for (int ps = 0; ps < 16 / RPP; ++ps) {
                 const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 4;
                 const int m = mrow0 + r;
-                f4 v = *reinterpret_cast<const f4 *>(patch + r * PS + c);
+                f4 v = *reinterpret_cast<const f4 *>(patch + pidx(r, c));
                 if (m < p.M) {
                     if (p.residual) {
                         const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
@@ -1199,7 +1206,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
             for (int ps = 0; ps < 16 / RPP; ++ps) {
                 const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 8;
                 const int m = mrow0 + r;
-                f4 lo = *reinterpret_cast<const f4 *>(patch + r * PS + c), hi = *reinterpret_cast<const f4 *>(patch + r * PS + c + 4);
+                f4 lo = *reinterpret_cast<const f4 *>(patch + pidx(r, c)), hi = *reinterpret_cast<const f4 *>(patch + pidx(r, c + 4));
                 if (m < p.M) {
                     if (p.residual) {
                         const float4 r0 = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
@@ -1621,7 +1628,13 @@ static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
     const int lds = 2 * (MT <= 4 ? 8 : 4) * 16 * MT * 128;
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_wide_kernel<MT, EPI>), lds);
     if (ea != hipSuccess) return ea;
-    OPUS_LAUNCH(KC_WIDE, (gemm_wide_kernel<MT, EPI>), dim3(blocks, ks), dim3(512), lds, s, p, ks);
+    if (ks > 1 && p.row_ssq) {       // k-parts leave raw slabs: the row scale is applied by whoever combines them, not here
+        GemmParams q = p;
+        q.row_ssq = nullptr;
+        OPUS_LAUNCH(KC_WIDE, (gemm_wide_kernel<MT, EPI>), dim3(blocks, ks), dim3(512), lds, s, q, ks);
+    } else {
+        OPUS_LAUNCH(KC_WIDE, (gemm_wide_kernel<MT, EPI>), dim3(blocks, ks), dim3(512), lds, s, p, ks);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1 || p.slab_only) return e;
     return launch_reduce<EPI>(p, ks, s);

@@ -1,16 +1,23 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run through gpurun from the repo root):
-#   bench line (C2 default), rocprofv3 kernel stats of the same command, PMC read / write passes (eager launches,
-#   one step: counters cannot be collected through hipGraph replays), and the batch-64 bench + stats.
+#   the bench line (default command: batch 64/GPU headline + configs[1] + projector stage), rocprofv3 kernel stats of the same
+#   command, PMC read / write passes (eager launches, one step: counters cannot be collected through hipGraph replays), the
+#   configs[2] (mixed lengths) and configs[4]-shape lines, and the two-stage pipeline demo under the kernel trace.
+# Raw traces are summarised on the box and deleted (gpurun copies back at most 64 MiB).
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.log && tail -c 600 $OUT/bench_c2.json &&
-rocprofv3 --kernel-trace --stats -d $OUT/stats_c2 -o c2 --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/stats_c2.log 2>&1 &&
-OPUS_NO_GRAPH=1 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OUT/pmc_rd -o rd --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/pmc_rd.log 2>&1 &&
-OPUS_NO_GRAPH=1 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_wr -o wr --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/pmc_wr.log 2>&1 &&
-python3 bench.py --batch 64 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_b64.json 2> $OUT/bench_b64.log &&
-rocprofv3 --kernel-trace --stats -d $OUT/stats_b64 -o b64 --output-format csv -- python3 bench.py --batch 64 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/stats_b64.log 2>&1 &&
-echo refresh done
+keep_stats() { find "$1" -name '*_kernel_stats.csv' -exec cp {} "$2" \; ; rm -rf "$1"; }
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.log && tail -c 300 $OUT/bench.json &&
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o main --output-format csv -- python3 bench.py --no-cpu-baseline --no-roofline > $OUT/stats.log 2>&1 &&
+keep_stats $OUT/stats $OUT/kernel_stats.csv &&
+OPUS_NO_GRAPH=1 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OUT/pmc_rd -o rd --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline > $OUT/pmc_rd.log 2>&1 &&
+OPUS_NO_GRAPH=1 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_wr -o wr --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline > $OUT/pmc_wr.log 2>&1 &&
+python3 tools/pmc_summary.py $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt && rm -rf $OUT/pmc_rd $OUT/pmc_wr &&
+python3 bench.py --mixed-lengths --steps 5 --warmup 2 --no-cpu-baseline --no-c2 > $OUT/bench_c3.json 2> $OUT/bench_c3.log &&
+python3 bench.py --model vicuna_13b --batch 32 --residues 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-c2 > $OUT/bench_c5.json 2> $OUT/bench_c5.log &&
+rocprofv3 --kernel-trace --stats -d $OUT/stats_two_stage -o ts --output-format csv -- python3 tools/two_stage_demo.py --n 4096 > $OUT/two_stage.log 2>&1 &&
+keep_stats $OUT/stats_two_stage $OUT/kernel_stats_two_stage.csv &&
+tail -1 $OUT/two_stage.log && du -sh $OUT && echo refresh done
