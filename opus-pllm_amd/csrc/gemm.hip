@@ -19,6 +19,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <utility>
 
@@ -1378,6 +1379,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
     }
 }
 
+// The same for EPI_NONE with N % 256 == 0 (the wo / down / fc2 reduces of the decode step and of the few-tile GEMMs): a lane
+// owns 4 consecutive columns - one 16-B load per slab, 16-B residual / output accesses - and a wave owns one 256-column block
+// of a row, so the block's sum of squares for the row-scale fusion is one wave reduction (no barrier).
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(GemmParams p, int ksplit) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (int64_t)p.M * p.N) return;                             // (whole waves: N % 256 == 0)
+    const int m = (int)(i / p.N), no = (int)(i % p.N);
+    const int64_t slab = (int64_t)p.M * p.N;
+    float rstd = 1.0f;
+    if (p.Af) {
+        float q = 0.f;
+        for (int k = 0; k < ksplit; ++k) q += p.ws[ksplit * slab + (int64_t)k * p.M + m];
+        rstd = rsqrtf(q / (float)p.K + p.norm_eps);
+    } else if (p.row_ssq) {
+        float q = 0.f;
+        for (int j = 0; j < p.row_nblk; ++j) q += p.row_ssq[m * p.row_nblk + j];
+        rstd = rsqrtf(q / (float)p.K + p.norm_eps);
+    }
+    f4 v = f4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < ksplit; ++k) {
+        const float4 t = *reinterpret_cast<const float4 *>(p.ws + k * slab + i);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        v[c] *= rstd;
+        if (p.bias) v[c] += p.bias[no + c];
+    }
+    if (p.residual) {
+        const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + no);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    }
+    if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + no) = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + no) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    if (p.xh_out) {
+        *reinterpret_cast<h4 *>(p.xh_out + (int64_t)m * p.N + no) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if ((threadIdx.x & 63) == 0) p.ssq_out[(int64_t)m * (p.N >> 8) + (no >> 8)] = q;
+    }
+}
+
 template <int EPI>
 static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s) {
     const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
@@ -1385,7 +1429,10 @@ static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s) {
     if (EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 && !p.Af && (p.N & 255) == 0) *p.fused_done = 1;
     else q.xh_out = nullptr;
     if (tl_launch_ev) tl_launch_ev->aux_bytes = 4.0 * ks * p.M * p.N + (double)p.M * nout * ((p.out_f32 ? 4 : 2) + (p.residual ? 4 : 0));
-    OPUS_LAUNCH(KC_REDUCE, (splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, q, ks);
+    if (EPI == EPI_NONE && (p.N & 255) == 0 && ((p.ldc | p.ldr) & 3) == 0)
+        OPUS_LAUNCH(KC_REDUCE, splitk_reduce4_kernel, dim3(cdiv((int64_t)p.M * p.N, 1024)), dim3(256), 0, s, q, ks);
+    else
+        OPUS_LAUNCH(KC_REDUCE, (splitk_reduce_kernel<EPI>), dim3(cdiv((int64_t)p.M * nout, 256)), dim3(256), 0, s, q, ks);
     return hipGetLastError();
 }
 
@@ -1493,15 +1540,19 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
         ld_nt(wl[u], wh[u], wp + (int64_t)cn * 1024);
     }
     int buf = 0, cs = c0;
-    // steady state: this stage is full and another one follows -> a branch-free body (DMA of the next stage, 8 x
-    // [MFMAs, clamped refill]).  With conditional loads or a conditional DMA the compiler cannot count what is in flight
-    // and drains the whole queue - the just-issued DMA included - in front of the stage's first MFMA.
-    for (; cs + SC < c1; cs += SC, buf ^= 1) {
+    // Full stages run a branch-free body (DMA of the next stage when there is one, 8 x [MFMAs, clamped refill]).  With
+    // conditional loads or a conditional DMA the compiler cannot count what is in flight and drains the whole queue - the
+    // just-issued DMA included - in front of the stage's first MFMA.  HAS_NEXT = false is the same body for a final FULL
+    // stage (nothing to prefetch): short k-parts (the QKV / wo GEMMs of the batched decode step: 8-16 chunks) then never touch
+    // the guarded path below, which is left to a genuinely partial last stage.
+    auto full_stage = [&](auto has_next_tag) {
+        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+        constexpr int PWN = HAS_NEXT ? PW : 0;
         // the DMA of this stage was issued before the (at most) 2 U weight loads still in flight
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * U) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's fragment reads of the other buffer
         __builtin_amdgcn_s_barrier();
-        dma_stage(buf ^ 1, cs + SC);
+        if (HAS_NEXT) dma_stage(buf ^ 1, cs + SC);
         const char *base = smem + buf * STAGE;
         // activation fragments of chunk u8+1 are read while chunk u8 is multiplied (two register sets, static parity)
         h8 fa[2][MT][2];
@@ -1520,7 +1571,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
             if (u8 + 1 < SC) read_chunk(u8 + 1, fa[(u8 + 1) & 1]);
             // younger than this chunk's pair (requested U chunks ago): the U-1 later refills, plus this stage's PW DMA
             // requests when the pair was requested before them (first U chunks of the stage)
-            if (u8 < U) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wl[u]), "+v"(wh[u]) : "n"(2 * (U - 1) + PW));
+            if (u8 < U) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wl[u]), "+v"(wh[u]) : "n"(2 * (U - 1) + PWN));
             else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wl[u]), "+v"(wh[u]) : "n"(2 * (U - 1)));
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -1532,12 +1583,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
             asm volatile("" : "+v"(wl[u]), "+v"(wh[u]));
             ld_nt(wl[u], wh[u], wp + (int64_t)cn * 1024);
         }
+    };
+    for (; cs + SC < c1; cs += SC, buf ^= 1) full_stage(std::true_type{});
+    if (cs + SC == c1) {
+        full_stage(std::false_type{});
+        cs += SC;
+        buf ^= 1;
     }
-    {   // last stage (possibly partial): guarded, everything in flight is retired first
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // everything the inline-asm loads have in flight is retired before the registers are handed back to the compiler
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wl[u]), "+v"(wh[u]));
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wl[u]), "+v"(wh[u]));
+    if (cs < c1) {   // partial last stage: guarded loads (its DMA, issued a stage ago, has landed: vmcnt(0) above)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const char *base = smem + buf * STAGE;

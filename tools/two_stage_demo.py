@@ -40,8 +40,14 @@ def main():
     ap.add_argument("--batch_size", type=int, default=64)
     ap.add_argument("--max_new_tokens", type=int, default=8)
     ap.add_argument("--decode_items", type=int, default=512, help="items of the shard that stage 2 also decodes (all are projected)")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "two_stage"))
+    ap.add_argument("--out", default=None, help="directory for the stage-1 .jsonl (default: a temporary one, removed at the end; "
+                                                "4096 items are ~100 MB of JSON)")
     a = ap.parse_args()
+    import tempfile
+    tmp = None
+    if a.out is None:
+        tmp = tempfile.TemporaryDirectory()
+        a.out = tmp.name
     os.makedirs(a.out, exist_ok=True)
     gen, ddp = load("generate_esm_embedding"), load("eval_ddp")
     tok, model, _ = load_pretrained_model(f"synthetic:{a.model}", "synthetic", a.model, device="cuda:0", max_batch=a.batch_size,
@@ -75,6 +81,8 @@ def main():
     print(json.dumps({"items": len(qs), "stage1_items_per_s": len(qs) / (t1 - t0), "stage2_items_per_s": ids.shape[0] / (t3 - t2),
                       "projector_rows": len(qs), "projector_gemm_ms": ms, "projector_tflops_per_launch_timestamps": fl / (ms * 1e-3) / 1e12,
                       "projector_launches": {k: v[1] for k, v in gemm.items()}}))
+    if tmp is not None:
+        tmp.cleanup()
 
 
 if __name__ == "__main__":
