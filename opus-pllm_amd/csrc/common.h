@@ -86,6 +86,7 @@ struct GemmParams {
     int slab_only = 0;
     int *ks_out = nullptr;
     int force_wide = 0;     // route a narrow output (N < 16384) through gemm_wide_kernel + k-parts
+    long long *trace = nullptr;   // tuning aid (OPUS_PP_TRACE): gemm_pp_kernel writes 4 wall-clock stamps per workgroup
 };
 
 // Flash-style attention over strided Q/K/V (fp16).  Q(b,h,t,:) = Q + b*q_sb + t*q_st + h*HD etc.;

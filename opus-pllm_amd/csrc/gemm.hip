@@ -954,6 +954,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     // tiles left over - a last, partly filled round that would cost a full tile time - are cut into `tail_split` k-parts each,
     // so that the round is as many workgroups but 1 / tail_split as long; the parts leave raw fp32 tiles in the workspace
     // for pp_tail_reduce_kernel (fixed summation order: bitwise reproducible).
+    if (p.trace && tid == 0) p.trace[blockIdx.x * 4] = wall_clock64();
     int bid = blockIdx.x, kpart = 0;
     const bool partial = bid >= full_tiles;
     if (!partial) {   // XCD-aware order, as the ring kernel
@@ -1076,6 +1077,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     if (NH >= D) vmcnt_wait<2 * (D - 4)>();
     else vmcnt_wait<0>();
     __builtin_amdgcn_s_barrier();
+    if (p.trace && tid == 0) p.trace[blockIdx.x * 4 + 1] = wall_clock64();
     if (wr == 1) __builtin_amdgcn_s_barrier();                        // wave-row 1 runs one barrier behind
     read_a(0, 0, a0);
 
@@ -1107,6 +1109,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                        // every wave executes the same number of barriers
+    if (p.trace && tid == 0) p.trace[blockIdx.x * 4 + 2] = wall_clock64();
 
     if (partial) {   // raw fp32 tile [256][256] of this k-part (rows / columns beyond M / N hold clamped-row products: never read)
         float *slab = p.ws + (((int64_t)(bid - full_tiles) * tail_split + kpart) << 16);
@@ -1151,33 +1154,97 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     constexpr bool XSW = NO == 64;
     constexpr int PS = XSW ? NO : NO + 4;
     auto pidx = [&](int r, int c) { return XSW ? r * PS + ((((c >> 2) ^ (r & 15)) << 2) | (c & 3)) : r * PS + c; };
+    // The bias of this lane's 16 GEMM columns is the same for all 8 row tiles, and the per-tile LDS round trip below is fenced
+    // with asm barriers the compiler will not move loads across: fetched once here, not once per row tile (8 dependent L2
+    // round trips, ~1 us each, were 3/4 of this epilogue).  The residual rows of tile i+1 are requested before tile i is
+    // processed for the same reason.
+    float bz[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        // 1. bias / activation in registers, 4 columns per lane -> patch[li][...]
+    for (int q = 0; q < 16; ++q) bz[q] = 0.f;
+    if (p.bias) {
         if (EPI == EPI_SILU_GU16) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int nb = n0 + wc * 64 + jj * 32 + 4 * g;        // gate columns in the GEMM's N space
-                f4 v;
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float gate = acc[i][2 * jj][r], up = acc[i][2 * jj + 1][r];
-                    if (p.bias) { gate += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
-                    v[r] = silu(gate) * up;
+                    const int nb = n0 + wc * 64 + jj * 32 + 4 * g + r;
+                    bz[jj * 8 + r] = p.bias[nb];
+                    bz[jj * 8 + 4 + r] = p.bias[nb + 16];
                 }
-                *reinterpret_cast<f4 *>(patch + pidx(li, jj * 16 + 4 * g)) = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bz[j * 4 + r] = p.bias[n0 + wc * 64 + j * 16 + 4 * g + r];
+        }
+    }
+    // residual pieces of one row tile: fp32 output - 16 / RPP passes of one float4; fp16 output - 16 / RPP passes of two
+    constexpr int LPR32 = NO / 4, RPP32 = 64 / LPR32, LPR16 = NO / 8, RPP16 = 64 / LPR16;
+    constexpr int NR = (16 / RPP32) > 2 * (16 / RPP16) ? (16 / RPP32) : 2 * (16 / RPP16);
+    auto load_res = [&](int i, float4 (&rr)[NR]) {
+        const int mrow0 = m0 + wr * 128 + i * 16;
+        if (p.out_f32) {
+#pragma unroll
+            for (int ps = 0; ps < 16 / RPP32; ++ps) {
+                const int r = ps * RPP32 + lane / LPR32, c = (lane % LPR32) * 4;
+                const int m = mrow0 + r < p.M ? mrow0 + r : p.M - 1;
+                rr[ps] = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nb = n0 + wc * 64 + j * 16 + 4 * g;
-                f4 v = acc[i][j];
+            for (int ps = 0; ps < 16 / RPP16; ++ps) {
+                const int r = ps * RPP16 + lane / LPR16, c = (lane % LPR16) * 8;
+                const int m = mrow0 + r < p.M ? mrow0 + r : p.M - 1;
+                rr[2 * ps] = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
+                rr[2 * ps + 1] = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c + 4);
+            }
+        }
+    };
+    // Two row tiles per LDS round trip (the wave's 16-KB region holds four 4-KB patch images; two keep the residual
+    // prefetch at 2 x 16 registers per stage): 4 serialized write -> wait -> read trips per tile instead of 8.
+    constexpr int RB = 2, PIMG = 16 * PS;
+    float4 rbuf[2][RB][NR];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (p.bias) v[r] += p.bias[nb + r];
-                    if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+        for (int u = 0; u < RB; ++u) rbuf[0][u][q] = rbuf[1][u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.residual) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) load_res(u, rbuf[0][u]);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 8 / RB; ++ib) {
+        if (p.residual && ib + 1 < 8 / RB) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) load_res((ib + 1) * RB + u, rbuf[(ib + 1) & 1][u]);
+        }
+        // 1. bias / activation in registers, 4 columns per lane -> patch image u, row li
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int i = ib * RB + u;
+            float *pu = patch + u * PIMG;
+            if (EPI == EPI_SILU_GU16) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    f4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gate = acc[i][2 * jj][r] + bz[jj * 8 + r], up = acc[i][2 * jj + 1][r] + bz[jj * 8 + 4 + r];
+                        v[r] = silu(gate) * up;
+                    }
+                    *reinterpret_cast<f4 *>(pu + pidx(li, jj * 16 + 4 * g)) = v;
                 }
-                *reinterpret_cast<f4 *>(patch + pidx(li, j * 16 + 4 * g)) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] += bz[j * 4 + r];
+                        if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
+                    }
+                    *reinterpret_cast<f4 *>(pu + pidx(li, j * 16 + 4 * g)) = v;
+                }
             }
         }
         // same-wave LDS round trip (in-order LDS queue); the fences keep the compiler from reordering across it
@@ -1185,43 +1252,46 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // 2. row segments: lane -> (row, 4- or 8-column piece)
-        const int mrow0 = m0 + wr * 128 + i * 16;
-        if (p.out_f32) {
-            constexpr int LPR = NO / 4, RPP = 64 / LPR;               // lanes per row, rows per pass
 #pragma unroll
-            for (int ps = 0; ps < 16 / RPP; ++ps) {
-                const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 4;
-                const int m = mrow0 + r;
-                f4 v = *reinterpret_cast<const f4 *>(patch + pidx(r, c));
-                if (m < p.M) {
-                    if (p.residual) {
-                        const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
+        for (int u = 0; u < RB; ++u) {
+            const int i = ib * RB + u;
+            const float *pu = patch + u * PIMG;
+            float4 (&rcur)[NR] = rbuf[ib & 1][u];
+            const int mrow0 = m0 + wr * 128 + i * 16;
+            if (p.out_f32) {
+#pragma unroll
+                for (int ps = 0; ps < 16 / RPP32; ++ps) {
+                    const int r = ps * RPP32 + lane / LPR32, c = (lane % LPR32) * 4;
+                    const int m = mrow0 + r;
+                    f4 v = *reinterpret_cast<const f4 *>(pu + pidx(r, c));
+                    if (m < p.M) {
+                        const float4 rr = rcur[ps];
                         v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + nw0 + c) = make_float4(v[0], v[1], v[2], v[3]);
                     }
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + nw0 + c) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-            }
-        } else {
-            constexpr int LPR = NO / 8, RPP = 64 / LPR;
+            } else {
 #pragma unroll
-            for (int ps = 0; ps < 16 / RPP; ++ps) {
-                const int r = ps * RPP + lane / LPR, c = (lane % LPR) * 8;
-                const int m = mrow0 + r;
-                f4 lo = *reinterpret_cast<const f4 *>(patch + pidx(r, c)), hi = *reinterpret_cast<const f4 *>(patch + pidx(r, c + 4));
-                if (m < p.M) {
-                    if (p.residual) {
-                        const float4 r0 = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c);
-                        const float4 r1 = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + nw0 + c + 4);
+                for (int ps = 0; ps < 16 / RPP16; ++ps) {
+                    const int r = ps * RPP16 + lane / LPR16, c = (lane % LPR16) * 8;
+                    const int m = mrow0 + r;
+                    f4 lo = *reinterpret_cast<const f4 *>(pu + pidx(r, c)), hi = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 4));
+                    if (m < p.M) {
+                        const float4 r0 = rcur[2 * ps], r1 = rcur[2 * ps + 1];
                         lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
                         hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
+                        *reinterpret_cast<h8 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c) =
+                            h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
                     }
-                    *reinterpret_cast<h8 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c) =
-                        h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
                 }
             }
         }
-        // the patch is rewritten by the next row tile: its reads above must have retired (same wave, in order)
+        // the patch images are rewritten by the next pair of row tiles: the reads above must have retired (same wave, in order)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (p.trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.trace[blockIdx.x * 4 + 3] = wall_clock64();
     }
 }
 
@@ -1319,6 +1389,35 @@ static hipError_t launch_pp(const GemmParams &p, hipStream_t s) {
         if (sp > 1) { full = T - R; split = sp; }
     }
     const int tail = T - full;
+    static const bool trace = getenv("OPUS_PP_TRACE") != nullptr;      // tuning aid: per-workgroup section times on stderr
+    if (trace) {
+        static long long *tb = nullptr;
+        const int nwg = full + tail * split;
+        if (!tb) (void)hipMalloc((void **)&tb, (size_t)(1 << 16) * 4 * sizeof(long long));
+        if (tb && nwg <= (1 << 16)) {
+            GemmParams q = p;
+            q.trace = tb;
+            hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(nwg), dim3(512), 8 * 16384, s, q, bm, bn, full, split);
+            (void)hipStreamSynchronize(s);
+            std::vector<long long> h((size_t)nwg * 4);
+            (void)hipMemcpy(h.data(), tb, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            long long t0 = h[0], t1 = h[3];
+            double pro = 0, mainl = 0, epi = 0;
+            for (int i = 0; i < nwg; ++i) {
+                t0 = std::min(t0, h[4 * i]); t1 = std::max(t1, h[4 * i + 3]);
+                if (i < full) { pro += h[4 * i + 1] - h[4 * i]; mainl += h[4 * i + 2] - h[4 * i + 1]; epi += h[4 * i + 3] - h[4 * i + 2]; }
+            }
+            // start-time gaps: for every workgroup after the first 256, the time between its start and the latest earlier end on...
+            // (unknown CU) - report instead the mean start time of each block of 256 workgroups relative to the kernel start
+            fprintf(stderr, "[pp trace] M=%d N=%d K=%d epi=%d wg=%d (full %d): kernel %.1f us; per full tile: prologue %.2f us, main %.2f us, epilogue %.2f us\n",
+                    p.M, p.N, p.K, EPI, nwg, full, (t1 - t0) * 0.01, pro / full * 0.01, mainl / full * 0.01, epi / full * 0.01);
+            for (int r0 = 0; r0 < nwg; r0 += 256) {
+                double st = 0, en = 0; int n = 0;
+                for (int i = r0; i < nwg && i < r0 + 256; ++i, ++n) { st += h[4 * i] - t0; en += h[4 * i + 3] - t0; }
+                fprintf(stderr, "   wg %5d..: mean start %.1f us, mean end %.1f us\n", r0, st / n * 0.01, en / n * 0.01);
+            }
+        }
+    }
     OPUS_LAUNCH(KC_PP, (gemm_pp_kernel<EPI>), dim3(full + tail * split), dim3(512), 8 * 16384, s, p, bm, bn, full, split);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || split == 1) return e;
@@ -1776,6 +1875,10 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     // Too few output tiles to fill 256 CUs (B = 1 prefill, single-protein encoder): split K so that
     // ~256-320 workgroups stream the weights, at least 4 k-tiles each, slabs within the workspace.
     const int ntile = tm * tn, KT = p.K / TBK;
+    // single-protein encoder shapes (514..4112 rows): the LDS-DMA ring at the same 128 x 128 tile keeps 3 k-steps in flight
+    // instead of one register prefetch: -0..20 % (tools/bench_gemm.py m96); <= 128 rows stay on the tile kernel (equal)
+    static const bool no_small_ring = getenv("OPUS_NO_SMALL_RING") != nullptr;   // A/B aid
+    if (p.M > 128 && !no_small_ring) return launch_ring<4, 2, 4, EPI>(p, s, true);
     int ks = 1;
     if (p.ws && ntile < 160) {
         ks = 320 / ntile;

@@ -93,6 +93,10 @@ if __name__ == "__main__":
         bench_tile("square 4096", 4096, 4096, 4096, 0)
         bench_tile("square 8192", 8192, 8192, 8192, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "custom":   # custom M N K epi f32out resid [iters]
+        a = [int(x) for x in sys.argv[2:]]
+        bench_tile("custom", a[0], a[1], a[2], a[3], bool(a[4]), bool(a[5]), iters=a[6] if len(a) > 6 else 20)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "proj":
         for M in (256, 512, 768, 1024, 2048, 4096):
             bench_tile("projector sw1 gelu", M, 32768, 5120, 1, iters=10)
