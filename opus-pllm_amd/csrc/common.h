@@ -86,6 +86,7 @@ struct GemmParams {
     int slab_only = 0;
     int *ks_out = nullptr;
     int force_wide = 0;     // route a narrow output (N < 16384) through gemm_wide_kernel + k-parts
+    int no_rot = 0;               // A/B aid (OPUS_NO_KROT): weight-streaming kernels walk k from chunk 0 in every workgroup
     long long *trace = nullptr;   // tuning aid (OPUS_PP_TRACE): gemm_pp_kernel writes 4 wall-clock stamps per workgroup
 };
 

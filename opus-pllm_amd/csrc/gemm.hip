@@ -98,11 +98,14 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
         constexpr int U = 4;
         // two NAMED register sets (a runtime-indexed [2][U] array would be placed in scratch)
         h8 wlA[U], whA[U], wlB[U], whB[U];
+        // (a rotated start as in gemm_wide_kernel was measured here too: neutral to -6 % at batch 1 - k-parts already spread
+        //  the waves of a workgroup over the panel)
+        auto phys = [&](int c) { return c; };
         auto wload = [&](h8 (&wl)[U], h8 (&wh)[U], int c) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (c + u < c1) {
-                    const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)(c + u) * 1024);
+                    const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)phys(c + u) * 1024);
                     wl[u] = __builtin_nontemporal_load(ptr);
                     wh[u] = __builtin_nontemporal_load(ptr + 64);
                 } else {
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
         auto compute = [&](const h8 (&wl)[U], const h8 (&wh)[U], int c) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int cc = c + u < c1 ? c + u : c1 - 1;
+                const int cc = phys(c + u < c1 ? c + u : c1 - 1);
                 const h8 al = xr[cc * 8], ah = xr[cc * 8 + 4];
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wl[u], acc[0], 0, 0, 0);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[u], acc[0], 0, 0, 0);
@@ -1579,10 +1582,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
         pc[j] = ch;
         psrc[j] = p.A + (int64_t)row * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
     }
+    // Rotated start.  Every panel starts K * 32 bytes after the previous one - 128 KB at K = 4096 - and all waves of the chip
+    // walk their panels at the same pace: at any moment every request has the same address modulo the panel stride, i.e.
+    // falls on the same few memory channels (K = 4224 streams 7 % faster than 4096 for this reason alone).  Workgroup b
+    // therefore walks its k-part from stage b % nstages and wraps around (+4 % at K = 4096; only the order of the fp32
+    // sums changes).  Whole stages only.
+    const int nck = c1 - c0;
+    const int rot = (p.no_rot || nck % SC || nck < 2 * SC) ? 0 : (int)((blockIdx.x * 3u + blockIdx.y) % (unsigned)(nck / SC)) * SC;
+    auto phys = [&](int c) { const int q = c + rot; return q < c1 ? q : q - nck; };
     auto dma_stage = [&](int buf, int c) {                            // chunks c .. c+SC-1 (clamped to the k-part)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            const int cc = c + pc[j] < c1 ? c + pc[j] : c1 - 1;
+            const int cc = phys(c + pc[j] < c1 ? c + pc[j] : c1 - 1);
             const int q = wave * PW + j;
             __builtin_amdgcn_global_load_lds((gptr_t)(psrc[j] + (int64_t)cc * 64),
                                              (lptr_t)(smem + buf * STAGE + q * 1024), 16, 0, 0);
@@ -1596,7 +1607,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
     h8 wl[U], wh[U];
     auto w_load = [&](int u, int c) {
         if (c < c1) {
-            const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)c * 1024);
+            const h8 *ptr = reinterpret_cast<const h8 *>(wp + (int64_t)phys(c) * 1024);
             wl[u] = __builtin_nontemporal_load(ptr);
             wh[u] = __builtin_nontemporal_load(ptr + 64);
         }
@@ -1635,7 +1646,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
     };                                                                  //  LDS fragment reads can be scheduled around it)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int cn = c0 + u < c1 ? c0 + u : c1 - 1;
+        const int cn = phys(c0 + u < c1 ? c0 + u : c1 - 1);
         ld_nt(wl[u], wh[u], wp + (int64_t)cn * 1024);
     }
     int buf = 0, cs = c0;
@@ -1677,7 +1688,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], fa[u8 & 1][i][0], acc[i], 0, 0, 0);   // C^T tile
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], fa[u8 & 1][i][1], acc[i], 0, 0, 0);
             }
-            const int cn = c + U < c1 ? c + U : c1 - 1;              // (clamped: a few redundant loads at the very end)
+            const int cn = phys(c + U < c1 ? c + U : c1 - 1);        // (clamped: a few redundant loads at the very end)
             // the refill overwrites registers the MFMAs above read: in/out operands order it behind them
             asm volatile("" : "+v"(wl[u]), "+v"(wh[u]));
             ld_nt(wl[u], wh[u], wp + (int64_t)cn * 1024);
@@ -1915,7 +1926,15 @@ bool gemm_goes_wide(int M, int N) {
     return M > MID_MAX_M || !no_mid;
 }
 
+static hipError_t launch_gemm_(const GemmParams &p, hipStream_t s, int *klass);
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
+    static const bool no_rot = getenv("OPUS_NO_KROT") != nullptr;       // A/B aid
+    if (!no_rot) return launch_gemm_(p, s, klass);
+    GemmParams q = p;
+    q.no_rot = 1;
+    return launch_gemm_(q, s, klass);
+}
+static hipError_t launch_gemm_(const GemmParams &p, hipStream_t s, int *klass) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 63) || (p.lda & 7)) return hipErrorInvalidValue;
     if (p.epi == EPI_SILU_GU16 && (p.N & 31)) return hipErrorInvalidValue;
     const bool skinny = p.M <= SKINNY_MAX_M;

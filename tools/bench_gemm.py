@@ -93,6 +93,16 @@ if __name__ == "__main__":
         bench_tile("square 4096", 4096, 4096, 4096, 0)
         bench_tile("square 8192", 8192, 8192, 8192, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cover":   # does CU coverage matter for the wide kernel?  (224 / 256 / 192 / 128 workgroups)
+        for N in (28672, 32768, 24576, 16384, 65536):
+            bench(f"wide gu N={N}", 64, N, 4096, 2, False)
+            bench(f"wide plain N={N}", 64, N, 4096, 0, False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "camp":    # does a power-of-two panel stride (K = 4096: 128 KB) cost bandwidth?
+        for K in (4096, 4160, 4224, 4608, 3968, 8192, 8256):
+            bench(f"wide gu K={K}", 64, 28672, K, 2, False)
+            bench(f"skinny gu K={K}", 1, 28672, K, 2, False)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "custom":   # custom M N K epi f32out resid [iters]
         a = [int(x) for x in sys.argv[2:]]
         bench_tile("custom", a[0], a[1], a[2], a[3], bool(a[4]), bool(a[5]), iters=a[6] if len(a) > 6 else 20)
