@@ -17,6 +17,7 @@
 // slot = T0 + *step is read from device memory so the same launch can be replayed from a hipGraph.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace opus {
 
@@ -84,44 +85,106 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 
     // ---- the new token's q / k / v (optionally: sum of the QKV GEMM's k-part slabs, RMSNorm row scale, bias), rotary on
     // the query heads and the key; stage them in LDS and append k, v to the cache ----
+    // Every global value this phase needs is REQUESTED before the first one is used: the row's sums of squares one block per
+    // lane (one round trip instead of row_nblk), then - per thread - cos / sin, bias and the ks slab terms of its (at most NE)
+    // rotary pairs and of its v element.  Written as "load, add, load, add" (a runtime-length loop over slabs, stores to the
+    // cache in between) this phase was a chain of ~30 dependent L2 round trips and two thirds of the kernel's time.
     float rstd = 1.0f;
     if (p.row_ssq) {
         float q = 0.f;
-        for (int j = 0; j < p.row_nblk; ++j) q += p.row_ssq[b * p.row_nblk + j];
+        for (int j0 = 0; j0 < p.row_nblk; j0 += 64) {
+            const int j = j0 + lane;
+            q += j < p.row_nblk ? p.row_ssq[b * p.row_nblk + j] : 0.f;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         rstd = rsqrtf(q / (float)p.K + p.eps);
     }
-    auto elem = [&](int64_t col) -> float {         // projection output (b, col) rounded to fp16, as the unfused GEMM stores it
-        if (p.slabs) {
-            float v = 0.f;
-            for (int k = 0; k < p.ks; ++k) v += p.slabs[k * p.slab_stride + b * ld + col];
-            v *= rstd;
-            if (p.bias) v += p.bias[col];
-            return (float)(half_t)v;
-        }
-        return (float)p.qkv[b * ld + col];
-    };
-    for (int i = tid; i < (GP + 1) * HALF; i += 256) {
-        const int j = i / HALF, d = i % HALF;
-        const int64_t col = j < GP ? (int64_t)(h0 + j) * HD : (int64_t)(p.nh + kvh) * HD;
-        const float c = p.cs[((int64_t)pos * HALF + d) * 2], sn = p.cs[((int64_t)pos * HALF + d) * 2 + 1];
-        const float a = elem(col + d), bb = elem(col + d + HALF);
-        const half_t lo = (half_t)(a * c - bb * sn), hi = (half_t)(bb * c + a * sn);
-        if (j < GP) {
-            sq[j * HDP + d] = lo;
-            sq[j * HDP + d + HALF] = hi;
-        } else {
-            sk[d] = lo;
-            sk[d + HALF] = hi;
-            if (writer) {
-                kcb[(int64_t)slot * HD + d] = lo;
-                kcb[(int64_t)slot * HD + d + HALF] = hi;
+    constexpr int NE = ((GP + 1) * HALF + 255) / 256;
+    auto stage = [&](auto ksn_tag) {
+        constexpr int KSN = decltype(ksn_tag)::value;          // number of slabs; 0: finished fp16 projections in p.qkv
+        constexpr int NT = KSN ? KSN : 1;
+        float ta[NE][NT], tb[NE][NT], tv[NT], cc[NE], sn[NE], ba[NE], bb2[NE], bv = 0.f;
+        int jj[NE], dd[NE];
+        bool ok[NE];
+        const bool vok = tid < HD;
+        const int64_t vcol = (int64_t)(p.nh + p.nkv + kvh) * HD + (vok ? tid : 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = tid + 256 * e;
+            ok[e] = i < (GP + 1) * HALF;
+            const int ii = ok[e] ? i : 0;
+            jj[e] = ii / HALF;
+            dd[e] = ii % HALF;
+            const int64_t col = (jj[e] < GP ? (int64_t)(h0 + jj[e]) * HD : (int64_t)(p.nh + kvh) * HD) + dd[e];
+            cc[e] = p.cs[((int64_t)pos * HALF + dd[e]) * 2];
+            sn[e] = p.cs[((int64_t)pos * HALF + dd[e]) * 2 + 1];
+            if (KSN) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    ta[e][k] = p.slabs[k * p.slab_stride + b * ld + col];
+                    tb[e][k] = p.slabs[k * p.slab_stride + b * ld + col + HALF];
+                }
+                ba[e] = p.bias ? p.bias[col] : 0.f;
+                bb2[e] = p.bias ? p.bias[col + HALF] : 0.f;
+            } else {
+                ta[e][0] = (float)p.qkv[b * ld + col];
+                tb[e][0] = (float)p.qkv[b * ld + col + HALF];
+                ba[e] = bb2[e] = 0.f;
             }
         }
-    }
-    for (int d = tid; d < HD; d += 256) {
-        const half_t v = (half_t)elem((int64_t)(p.nh + p.nkv + kvh) * HD + d);
-        sv[d] = v;
-        if (writer) vcb[(int64_t)slot * HD + d] = v;
+        if (KSN) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) tv[k] = p.slabs[k * p.slab_stride + b * ld + vcol];
+            bv = p.bias ? p.bias[vcol] : 0.f;
+        } else {
+            tv[0] = (float)p.qkv[b * ld + vcol];
+        }
+        // projection output rounded to fp16, as the unfused GEMM stores it
+        auto fin = [&](const float (&t)[NT], float bias) -> float {
+            if (!KSN) return t[0];
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) v += t[k];
+            v *= rstd;
+            if (p.bias) v += bias;
+            return (float)(half_t)v;
+        };
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (!ok[e]) continue;
+            const float a = fin(ta[e], ba[e]), bb = fin(tb[e], bb2[e]);
+            const half_t lo = (half_t)(a * cc[e] - bb * sn[e]), hi = (half_t)(bb * cc[e] + a * sn[e]);
+            const int j = jj[e], d = dd[e];
+            if (j < GP) {
+                sq[j * HDP + d] = lo;
+                sq[j * HDP + d + HALF] = hi;
+            } else {
+                sk[d] = lo;
+                sk[d + HALF] = hi;
+                if (writer) {
+                    kcb[(int64_t)slot * HD + d] = lo;
+                    kcb[(int64_t)slot * HD + d + HALF] = hi;
+                }
+            }
+        }
+        if (vok) {
+            const half_t v = (half_t)fin(tv, bv);
+            sv[tid] = v;
+            if (writer) vcb[(int64_t)slot * HD + tid] = v;
+        }
+    };
+    static_assert(HD <= 256, "one v element per thread");
+    switch (p.slabs ? p.ks : 0) {
+        case 0: stage(std::integral_constant<int, 0>{}); break;
+        case 1: stage(std::integral_constant<int, 1>{}); break;
+        case 2: stage(std::integral_constant<int, 2>{}); break;
+        case 3: stage(std::integral_constant<int, 3>{}); break;
+        case 4: stage(std::integral_constant<int, 4>{}); break;
+        case 5: stage(std::integral_constant<int, 5>{}); break;
+        case 6: stage(std::integral_constant<int, 6>{}); break;
+        case 7: stage(std::integral_constant<int, 7>{}); break;
+        default: stage(std::integral_constant<int, 8>{}); break;   // launch_attn_decode rejects ks > 8
     }
     if (HD < HDP) {                                  // zero padding of the 32-wide MFMA k extent
         for (int i = tid; i < (GP + 1) * (HDP - HD); i += 256) {
@@ -290,6 +353,7 @@ static hipError_t launch_hd(const AttnDecodeParams &p, int B, hipStream_t s) {
 hipError_t launch_attn_decode(const AttnDecodeParams &p, int B, int hd, hipStream_t s) {
     const int G = p.nh / p.nkv;
     if (G > MAXG || G * p.nkv != p.nh) return hipErrorInvalidValue;
+    if (p.slabs && (p.ks < 1 || p.ks > 8)) return hipErrorInvalidValue;
     switch (hd) {
         case 16: return launch_hd<16>(p, B, s);
         case 32: return launch_hd<32>(p, B, s);

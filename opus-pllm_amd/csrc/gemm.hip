@@ -1323,12 +1323,30 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
 #pragma unroll
     for (int i = 0; i < RW; ++i) v[i] = f4{0.f, 0.f, 0.f, 0.f};
     const int r0 = blockIdx.y * 32 + wave * RW;
-    for (int k = 0; k < tail_split; ++k) {
+    for (int k0 = 0; k0 < tail_split; k0 += 4) {                      // 4 parts x 8 rows requested at a time, added in part order
+        float4 t[4][RW];
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const float4 t = *reinterpret_cast<const float4 *>(base + ((int64_t)k << 16) + (r0 + i) * 256);
-            v[i][0] += t.x; v[i][1] += t.y; v[i][2] += t.z; v[i][3] += t.w;
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + u < tail_split ? k0 + u : tail_split - 1;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) t[u][i] = *reinterpret_cast<const float4 *>(base + ((int64_t)kk << 16) + (r0 + i) * 256);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u >= tail_split) continue;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) { v[i][0] += t[u][i].x; v[i][1] += t[u][i].y; v[i][2] += t[u][i].z; v[i][3] += t[u][i].w; }
+        }
+    }
+    // residual rows of the 16-B path: requested together, ahead of the stores they would otherwise queue behind
+    const int no_v = EPI == EPI_SILU_GU16 ? ((n >> 5) << 4) + (n & 15) : n;
+    const bool vec_ok = no_v + 3 < (EPI == EPI_SILU_GU16 ? p.N / 2 : p.N) && ((p.ldc | p.ldr) & 3) == 0;
+    float4 rres[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int m = tm * 256 + r0 + i;
+        rres[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.residual && vec_ok && m < p.M) rres[i] = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + no_v);
     }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
@@ -1354,9 +1372,9 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
         }
         if (!live) continue;
         const int nlim = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
-        if (no + 3 < nlim && ((p.ldc | p.ldr) & 3) == 0) {
+        if (vec_ok) {
             if (p.residual) {
-                const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + no);
+                const float4 rr = rres[i];
                 x[0] += rr.x; x[1] += rr.y; x[2] += rr.z; x[3] += rr.w;
             }
             if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + no) = make_float4(x[0], x[1], x[2], x[3]);
@@ -1451,9 +1469,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
     if (EPI == EPI_SILU_GU16) {
         const int n = (no >> 4) * 32 + (no & 15);
         float gate = 0.f, up = 0.f;
-        for (int k = 0; k < ksplit; ++k) {
-            gate += p.ws[k * slab + (int64_t)m * p.N + n];
-            up += p.ws[k * slab + (int64_t)m * p.N + n + 16];
+        for (int k0 = 0; k0 < ksplit; k0 += 8) {                      // 8 slabs requested at a time, added in index order
+            float tg[8], tu[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k0 + u < ksplit ? k0 + u : ksplit - 1;
+                tg[u] = p.ws[kk * slab + (int64_t)m * p.N + n];
+                tu[u] = p.ws[kk * slab + (int64_t)m * p.N + n + 16];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < ksplit) { gate += tg[u]; up += tu[u]; }
         }
         gate *= rstd;
         up *= rstd;
@@ -1461,7 +1487,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
         v = silu(gate) * up;
     } else {
         v = 0.f;
-        for (int k = 0; k < ksplit; ++k) v += p.ws[k * slab + (int64_t)m * p.N + no];
+        for (int k0 = 0; k0 < ksplit; k0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k0 + u < ksplit ? k0 + u : ksplit - 1;
+                t[u] = p.ws[kk * slab + (int64_t)m * p.N + no];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < ksplit) v += t[u];
+        }
         v *= rstd;
         if (p.bias) v += p.bias[no];
         if (EPI == EPI_GELU) v = gelu_erf(v);
@@ -1499,20 +1535,33 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(GemmParams p, int k
         for (int j = 0; j < p.row_nblk; ++j) q += p.row_ssq[m * p.row_nblk + j];
         rstd = rsqrtf(q / (float)p.K + p.norm_eps);
     }
+    // every load of the kernel is requested before the first sum (a `load, add` loop over the slabs is ksplit dependent round
+    // trips: at 8 slabs that chain, not the 10 MB moved, was the kernel's 5 us); slabs are still added in index order
+    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+    f4 bz = f4{0.f, 0.f, 0.f, 0.f};
+    if (p.residual) rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + no);
+    if (p.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bz[c] = p.bias[no + c];
+    }
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < ksplit; ++k) {
-        const float4 t = *reinterpret_cast<const float4 *>(p.ws + k * slab + i);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    for (int k0 = 0; k0 < ksplit; k0 += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k0 + u < ksplit ? k0 + u : ksplit - 1;
+            t[u] = *reinterpret_cast<const float4 *>(p.ws + kk * slab + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < ksplit) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         v[c] *= rstd;
-        if (p.bias) v[c] += p.bias[no + c];
+        if (p.bias) v[c] += bz[c];
     }
-    if (p.residual) {
-        const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + no);
-        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-    }
+    if (p.residual) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
     if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + no) = make_float4(v[0], v[1], v[2], v[3]);
     else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + no) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
     if (p.xh_out) {
