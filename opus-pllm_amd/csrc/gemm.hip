@@ -98,9 +98,12 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
         constexpr int U = 4;
         // two NAMED register sets (a runtime-indexed [2][U] array would be placed in scratch)
         h8 wlA[U], whA[U], wlB[U], whB[U];
-        // (a rotated start as in gemm_wide_kernel was measured here too: neutral to -6 % at batch 1 - k-parts already spread
-        //  the waves of a workgroup over the panel)
-        auto phys = [&](int c) { return c; };
+        // rotated start of every wave's k-range (see gemm_wide_kernel: panel stride = 128 KB at K = 4096 puts the whole chip on
+        // the same memory channels).  Single-GEMM timings are within noise either way; the batch-1 step as a whole is 3.5 %
+        // faster (109.8 -> 106.0 ms, two alternating runs each).
+        const int nck = c1 - c0;
+        const int rot = (!p.no_rot && nck >= 2) ? (int)((blockIdx.x * 5u + wave * 3u) % (unsigned)nck) : 0;
+        auto phys = [&](int c) { const int q = c + rot; return q < c1 ? q : q - nck; };
         auto wload = [&](h8 (&wl)[U], h8 (&wh)[U], int c) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -793,12 +796,16 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_
         pn = pn < npanels ? pn : npanels - 1;
         srcB[j] = p.W + ((int64_t)pn * KT64) * 1024 + lane * 8;
     }
+    // rotated k-walk of the weight-streaming configuration (k-parts: the batched decode wo / down), as in gemm_wide_kernel;
+    // a function of the COLUMN block and k-part only, so that a row's result does not depend on which rows share its launch
+    const int krot = (ksplit > 1 && !p.no_rot && KS >= 2) ? (int)((unsigned)(tn * 3 + ky) % (unsigned)KS) : 0;
     auto stage_load = [&](int ks) {                                   // ks relative to s0
         char *base = smem + (ks % NS) * STAGE;
-        const int ka = s0 + ks;
+        const int kr = ks + krot < KS ? ks + krot : ks + krot - KS;   // k-step actually fetched into slot ks % NS
+        const int ka = s0 + kr;
 #pragma unroll
         for (int j = 0; j < CA; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + (int64_t)ks * GBK), (lptr_t)(base + ldsA[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + (int64_t)kr * GBK), (lptr_t)(base + ldsA[j]), 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < CB; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (int64_t)(ka >> 1) * 1024 + (ka & 1) * 512),
