@@ -105,6 +105,10 @@ struct opus_ctx {
     // row-scale fusion (GemmParams::xh_out / row_ssq): one-shot request for the next gemm() and its outcome
     half_t *rq_xh = nullptr;
     int rq_done = 0;
+    // one-shot request: fuse the ESM rotary into the next GEMM's epilogue (GemmParams::rope_*); rq_rope_done reports back
+    const float *rq_rope_cs = nullptr;
+    int rq_rope_T = 0, rq_rope_cols = 0, rq_rope_qcols = 0, rq_rope_done = 0;
+    float rq_rope_qscale = 1.0f;
     // one-shot requests for the next gemm(): route a narrow output through the wide kernel / leave raw k-part slabs
     int rq_force_wide = 0, rq_slab_only = 0, rq_ks = 1;
     const float *xh_src = nullptr;       // fp32 buffer whose fp16 copy + sum-of-squares partials are valid
@@ -462,6 +466,10 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     p.xh_out = c->rq_xh; p.ssq_out = c->d_ssq; p.fused_done = &c->rq_done;
     c->rq_done = 0;
     c->rq_xh = nullptr;                  // one-shot
+    p.rope_cs = c->rq_rope_cs; p.rope_T = c->rq_rope_T; p.rope_cols = c->rq_rope_cols; p.rope_qcols = c->rq_rope_qcols;
+    p.rope_qscale = c->rq_rope_qscale; p.rope_done = &c->rq_rope_done;
+    c->rq_rope_done = 0;
+    c->rq_rope_cs = nullptr;             // one-shot
     p.row_ssq = nullptr; p.row_nblk = 0;
     if (c->use_row_scale) { p.row_ssq = c->d_ssq; p.row_nblk = K >> 8; p.norm_eps = c->row_eps; c->use_row_scale = false; }
     c->rq_ks = 1;
@@ -573,8 +581,15 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
     for (int l = 0; l < g.enc_layers; ++l) {
         const EncLayer &L = c->enc[l];
         KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, L.ln1w, L.ln1b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
+        // q <- rotary(q * hd^-0.5), k <- rotary(k): in the projection's epilogue when the big tiled kernel takes it (head_dim 64),
+        // else by the stand-alone kernel on the stored projection (same arithmetic)
+        if (hd == 64) {
+            c->rq_rope_cs = c->cs_enc; c->rq_rope_T = T; c->rq_rope_cols = 2 * D; c->rq_rope_qcols = D;
+            c->rq_rope_qscale = 1.0f / sqrtf((float)hd);
+        }
         OPC(gemm(c, s, c->e_xn, D, L.wqkv, M, 3 * D, D, L.bqkv, EPI_NONE, nullptr, c->e_qkv, 3 * D, 0));
-        KL(KC_OTHER, 8.0 * M * D, launch_esm_rope(c->e_qkv, c->cs_enc, B, T, nh, hd, 1.0f / sqrtf((float)hd), s));
+        if (!c->rq_rope_done)
+            KL(KC_OTHER, 8.0 * M * D, launch_esm_rope(c->e_qkv, c->cs_enc, B, T, nh, hd, 1.0f / sqrtf((float)hd), s));
         AttnParams a;
         a.Q = c->e_qkv; a.K = c->e_qkv + D; a.V = c->e_qkv + 2 * D;
         a.q_sb = a.k_sb = a.v_sb = (int64_t)T * 3 * D;

@@ -86,6 +86,14 @@ struct GemmParams {
     int slab_only = 0;
     int *ks_out = nullptr;
     int force_wide = 0;     // route a narrow output (N < 16384) through gemm_wide_kernel + k-parts
+    // ESM rotary fused into the epilogue of the QKV projection (gemm_pp_kernel, head_dim 64, fp16 output): columns
+    // < rope_cols are rotated in heads of 64 - pairs (d, d + 32), angle of position (row % rope_T) from the [T][32][2]
+    // (cos, sin) table - after the usual rounding to fp16, columns < rope_qcols being scaled by rope_qscale first: the same
+    // arithmetic as esm_rope_kernel on the stored projection.  *rope_done = 1 when the launch applied it.
+    const float *rope_cs = nullptr;
+    int rope_T = 0, rope_cols = 0, rope_qcols = 0;
+    float rope_qscale = 1.0f;
+    int *rope_done = nullptr;
     int no_rot = 0;               // A/B aid (OPUS_NO_KROT): weight-streaming kernels walk k from chunk 0 in every workgroup
     long long *trace = nullptr;   // tuning aid (OPUS_PP_TRACE): gemm_pp_kernel writes 4 wall-clock stamps per workgroup
 };

@@ -1213,6 +1213,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     // Two row tiles per LDS round trip (the wave's 16-KB region holds four 4-KB patch images; two keep the residual
     // prefetch at 2 x 16 registers per stage): 4 serialized write -> wait -> read trips per tile instead of 8.
     constexpr int RB = 2, PIMG = 16 * PS;
+    // Fused ESM rotary (GemmParams::rope_cs; the host side guarantees EPI_NONE, fp16 output, no residual, no ragged edge):
+    // this wave's 64 columns are one head.  A lane then owns row lane / 4 and the 8 + 8 columns of four rotary pairs'
+    // worth of dims (8 pc .. 8 pc + 7 and the same + 32) and needs 8 (cos, sin) pairs = 4 float4 of the table per row tile,
+    // fetched a stage ahead through the (unused) residual slots.
+    constexpr bool ROPE_OK = EPI == EPI_NONE && NO == 64 && NR >= 4;
+    const bool rope_on = ROPE_OK && p.rope_cs != nullptr && !p.out_f32 && nw0 < p.rope_cols;   // wave-uniform
+    auto load_cs = [&](int i, float4 (&rr)[NR]) {
+        if constexpr (ROPE_OK) {
+            const int mb = m0 + wr * 128 + i * 16;
+            int t = __builtin_amdgcn_readfirstlane(mb % p.rope_T) + (lane >> 2);
+            while (t >= p.rope_T) t -= p.rope_T;
+            const float4 *src = reinterpret_cast<const float4 *>(p.rope_cs + ((int64_t)t * 32 + (lane & 3) * 8) * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rr[q] = src[q];
+        }
+    };
     float4 rbuf[2][RB][NR];
 #pragma unroll
     for (int q = 0; q < NR; ++q)
@@ -1221,12 +1237,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     if (p.residual) {
 #pragma unroll
         for (int u = 0; u < RB; ++u) load_res(u, rbuf[0][u]);
+    } else if (rope_on) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) load_cs(u, rbuf[0][u]);
     }
 #pragma unroll
     for (int ib = 0; ib < 8 / RB; ++ib) {
         if (p.residual && ib + 1 < 8 / RB) {
 #pragma unroll
             for (int u = 0; u < RB; ++u) load_res((ib + 1) * RB + u, rbuf[(ib + 1) & 1][u]);
+        } else if (rope_on && ib + 1 < 8 / RB) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) load_cs((ib + 1) * RB + u, rbuf[(ib + 1) & 1][u]);
         }
         // 1. bias / activation in registers, 4 columns per lane -> patch image u, row li
 #pragma unroll
@@ -1281,17 +1303,46 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                     }
                 }
             } else {
+                bool rotated = false;
+                if constexpr (ROPE_OK) {
+                    if (rope_on) {
+                        rotated = true;
+                        const int r = lane >> 2, c = (lane & 3) * 8;
+                        const int m = mrow0 + r;
+                        const f4 l0 = *reinterpret_cast<const f4 *>(pu + pidx(r, c)), l1 = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 4));
+                        const f4 h0 = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 32)), h1 = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 36));
+                        const float qs = nw0 < p.rope_qcols ? p.rope_qscale : 1.0f;
+                        const float csv[16] = {rcur[0].x, rcur[0].y, rcur[0].z, rcur[0].w, rcur[1].x, rcur[1].y, rcur[1].z, rcur[1].w,
+                                               rcur[2].x, rcur[2].y, rcur[2].z, rcur[2].w, rcur[3].x, rcur[3].y, rcur[3].z, rcur[3].w};
+                        h8 olo, ohi;
 #pragma unroll
-                for (int ps = 0; ps < 16 / RPP16; ++ps) {
-                    const int r = ps * RPP16 + lane / LPR16, c = (lane % LPR16) * 8;
-                    const int m = mrow0 + r;
-                    f4 lo = *reinterpret_cast<const f4 *>(pu + pidx(r, c)), hi = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 4));
-                    if (m < p.M) {
-                        const float4 r0 = rcur[2 * ps], r1 = rcur[2 * ps + 1];
-                        lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
-                        hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
-                        *reinterpret_cast<h8 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c) =
-                            h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+                        for (int e = 0; e < 8; ++e) {
+                            // the projection is rounded to fp16 first, exactly as it is when stored and rotated by esm_rope_kernel
+                            const float a = (float)(half_t)(e < 4 ? l0[e] : l1[e - 4]) * qs, b = (float)(half_t)(e < 4 ? h0[e] : h1[e - 4]) * qs;
+                            const float cc = csv[2 * e], sn = csv[2 * e + 1];
+                            olo[e] = (half_t)(a * cc - b * sn);
+                            ohi[e] = (half_t)(b * cc + a * sn);
+                        }
+                        if (m < p.M) {
+                            half_t *dst = reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c;
+                            *reinterpret_cast<h8 *>(dst) = olo;
+                            *reinterpret_cast<h8 *>(dst + 32) = ohi;
+                        }
+                    }
+                }
+                if (!rotated) {
+#pragma unroll
+                    for (int ps = 0; ps < 16 / RPP16; ++ps) {
+                        const int r = ps * RPP16 + lane / LPR16, c = (lane % LPR16) * 8;
+                        const int m = mrow0 + r;
+                        f4 lo = *reinterpret_cast<const f4 *>(pu + pidx(r, c)), hi = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 4));
+                        if (m < p.M) {
+                            const float4 r0 = rcur[2 * ps], r1 = rcur[2 * ps + 1];
+                            lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
+                            hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
+                            *reinterpret_cast<h8 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c) =
+                                h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+                        }
                     }
                 }
             }
@@ -1400,7 +1451,8 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
 }
 
 template <int EPI>
-static hipError_t launch_pp(const GemmParams &p, hipStream_t s) {
+static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
+    GemmParams p = p_in;
     const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_pp_kernel<EPI>), 8 * 16384);
     if (ea != hipSuccess) return ea;
@@ -1408,8 +1460,14 @@ static hipError_t launch_pp(const GemmParams &p, hipStream_t s) {
     const int T = bm * bn, KT = p.K >> 6;
     int full = T, split = 1;
     static const bool no_tail = getenv("OPUS_NO_PP_TAIL") != nullptr;   // A/B aid
+    // fused rotary: every wave must take the 16-B row-segment path and every tile this kernel's own epilogue
+    static const bool no_rope_fuse = getenv("OPUS_NO_ROPE_FUSION") != nullptr;   // A/B aid
+    const bool rope = p.rope_cs && p.rope_done && !no_rope_fuse && EPI == EPI_NONE && !p.out_f32 && !p.residual && (p.ldc & 7) == 0 &&
+                      (p.N & 255) == 0 && (p.rope_cols & 63) == 0 && (p.rope_qcols & 63) == 0 && p.rope_T > 0;
+    if (rope) *p.rope_done = 1;
+    else p.rope_cs = nullptr;
     const int R = T % 256;
-    if (!no_tail && p.ws && T > 256 && R > 0 && R <= 128) {
+    if (!no_tail && !rope && p.ws && T > 256 && R > 0 && R <= 128) {
         int sp = 256 / R;
         sp = sp > 8 ? 8 : sp;
         if (sp > KT / 4) sp = KT / 4;                                 // at least 4 k-tiles per part (pipeline prologue)
