@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 3
+#define OPUS_ABI_VERSION 4
 
 enum opus_status {
     OPUS_OK = 0,
@@ -178,6 +178,12 @@ int opus_debug_gemm_norm(opus_ctx *ctx, const float *d_A, const void *d_W, void 
 int opus_debug_gemm_rowscale(opus_ctx *ctx, const void *d_A, const void *d_W1, float *d_X, const void *d_W2, void *d_C,
                              int32_t M, int32_t N1, int32_t K1, int32_t N2, int32_t epi, float eps, int32_t *fused,
                              void *stream);
+/* The ESM-2 QKV projection + rotary as opus_esm2_encode issues it: out[M, 3 D] fp16 = rotary(A[M,K] W[3 D,K]^T + bias), query
+ * third scaled by head_dim^-0.5 before the rotation, position of row m = m % T (cstp_v3 / modeling_esm.py:374, rotary
+ * embedding).  The context's encoder head_dim must equal D / heads.  allow_fuse = 0 forces the stand-alone rotary kernel on
+ * the stored projection; *fused (HOST) = 1 when the rotation ran in the GEMM's epilogue (large M, head_dim 64). */
+int opus_debug_gemm_rope(opus_ctx *ctx, const void *d_A, const void *d_W, const float *d_bias, void *d_out, int32_t M,
+                         int32_t D, int32_t K, int32_t T, int32_t heads, int32_t allow_fuse, int32_t *fused, void *stream);
 int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const void *d_V, void *d_O,
                          const int32_t *d_kstart, const int32_t *d_kend, int32_t B, int32_t T, int32_t heads,
                          int32_t group, int32_t head_dim, int32_t causal, float scale, void *stream);

@@ -1140,6 +1140,30 @@ extern "C" int opus_debug_gemm_norm(opus_ctx *c, const float *A, const void *W, 
                     out_f32);
 }
 
+// The ESM QKV projection + rotary exactly as opus_esm2_encode issues it: out[M, 3 D] fp16 = rotary(A W^T + bias) with the
+// query third scaled by head_dim^-0.5, positions row % T.  allow_fuse = 0 forces the stand-alone rotary kernel on the stored
+// projection; *fused (HOST) = 1 when the GEMM's epilogue did the rotation.
+extern "C" int opus_debug_gemm_rope(opus_ctx *c, const void *A, const void *W, const float *bias, void *out, int32_t M,
+                                    int32_t D, int32_t K, int32_t T, int32_t heads, int32_t allow_fuse, int32_t *fused,
+                                    void *stream) {
+    if (!c || !A || !W || !out || !fused) return fail(OPUS_EBADARG, "debug_gemm_rope: null pointer");
+    if (M < 1 || D < 16 || K < 64 || K % 64 || T < 1 || heads < 1 || D % heads || M % T)
+        return fail(OPUS_ESHAPE, "debug_gemm_rope: M %% T == 0, D %% heads == 0, K %% 64 == 0");
+    const int hd = D / heads;
+    if (hd != c->cfg.enc_dim / c->cfg.enc_heads || T > c->cfg.max_enc_tokens)
+        return fail(OPUS_ESHAPE, "debug_gemm_rope: head_dim / T must match the context's encoder rotary table");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const float qs = 1.0f / sqrtf((float)hd);
+    if (allow_fuse && hd == 64) {
+        c->rq_rope_cs = c->cs_enc; c->rq_rope_T = T; c->rq_rope_cols = 2 * D; c->rq_rope_qcols = D; c->rq_rope_qscale = qs;
+    }
+    OPC(gemm(c, s, (const half_t *)A, K, (const half_t *)W, M, 3 * D, K, bias, EPI_NONE, nullptr, out, 3 * D, 0));
+    *fused = c->rq_rope_done;
+    if (!c->rq_rope_done) HIPC(launch_esm_rope((half_t *)out, c->cs_enc, M / T, T, heads, hd, qs, s));
+    return OPUS_OK;
+}
+
 // The producer / consumer pair of the row-scale RMSNorm fusion exactly as prefill() and decode_step() issue it:
 //   X <- X + A W1^T            (wo: a split-K GEMM whose reduce also writes fp16(X) and per-256-column sums of squares)
 //   C  = epi(rmsnorm(X) W2^T)  (gate/up or lm_head: gemm_wide_kernel scales its rows by the rstd from those sums)

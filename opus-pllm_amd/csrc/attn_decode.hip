@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         for (int e = 0; e < NE; ++e) {
             if (!ok[e]) continue;
             const float a = fin(ta[e], ba[e]), bb = fin(tb[e], bb2[e]);
-            const half_t lo = (half_t)(a * cc[e] - bb * sn[e]), hi = (half_t)(bb * cc[e] + a * sn[e]);
+            float rl, rh;
+            rotate_pair(a, bb, cc[e], sn[e], rl, rh);              // (same arithmetic as the prefill's rotary kernel)
+            const half_t lo = (half_t)rl, hi = (half_t)rh;
             const int j = jj[e], d = dd[e];
             if (j < GP) {
                 sq[j * HDP + d] = lo;

@@ -55,6 +55,17 @@ hipError_t ensure_dyn_lds(const void *fn, size_t bytes);
 
 // C[M,Nout] = epi(A[M,K] * W[N,K]^T + bias) (+ residual).  fp16 operands, fp32 accumulate.
 // EPI_SILU_GU16: W rows come in 32-row groups [16 gate | 16 up]; Nout = N/2, out = silu(g) * u.
+// One rotary pair, with the contraction spelled out (one rounded product, one fused multiply-add) so that every kernel
+// that rotates - the stand-alone kernels and the fused GEMM epilogue - produces the same bits from the same inputs.
+// The results are pinned in fp32 registers: left to itself the compiler folds a following conversion to fp16 into the
+// multiply-add (v_fma_mixlo_f16: ONE rounding, straight to fp16) in some kernels and not in others - a 1-ulp difference in
+// 6e-5 of the elements; fp32 first, then fp16, is also what the reference's fp32 rotary followed by .to(fp16) does.
+__device__ __forceinline__ void rotate_pair(float a, float b, float c, float sn, float &lo, float &hi) {
+    lo = __builtin_fmaf(a, c, -__fmul_rn(b, sn));
+    hi = __builtin_fmaf(b, c, __fmul_rn(a, sn));
+    asm volatile("" : "+v"(lo), "+v"(hi));
+}
+
 struct GemmParams {
     const half_t *A;        // fp16 activations [M,K] (row-major, lda), or
     const float *Af;        // fp32 residual stream [M,K]: fused RMSNorm (skinny kernel only), else nullptr

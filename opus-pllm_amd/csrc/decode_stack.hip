@@ -400,7 +400,9 @@ __global__ __launch_bounds__(NT) void decode_stack_kernel(StackParams p) {
                 const unsigned short ua = __hip_atomic_load(reinterpret_cast<const unsigned short *>(src + dd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned short ub = __hip_atomic_load(reinterpret_cast<const unsigned short *>(src + dd + HALF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const float a = (float)__builtin_bit_cast(half_t, ua), bb = (float)__builtin_bit_cast(half_t, ub);
-                const half_t lo = (half_t)(a * cc - bb * sn), hi = (half_t)(bb * cc + a * sn);
+                float rl, rh;
+                rotate_pair(a, bb, cc, sn, rl, rh);
+                const half_t lo = (half_t)rl, hi = (half_t)rh;
                 if (j == 0) {
                     sq[dd] = (float)lo;
                     sq[dd + HALF] = (float)hi;

@@ -60,8 +60,10 @@ __device__ __forceinline__ void rope8(half_t *base, int half, const float *cs, f
     for (int j = 0; j < 8; ++j) {
         const float c = cs[2 * j], sn = cs[2 * j + 1];
         const float a = (float)lo[j] * scale, b = (float)hi[j] * scale;
-        olo[j] = (half_t)(a * c - b * sn);
-        ohi[j] = (half_t)(b * c + a * sn);
+        float rl, rh;
+        rotate_pair(a, b, c, sn, rl, rh);
+        olo[j] = (half_t)rl;
+        ohi[j] = (half_t)rh;
     }
     *reinterpret_cast<h8 *>(base) = olo;
     *reinterpret_cast<h8 *>(base + half) = ohi;

@@ -1320,8 +1320,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                             // the projection is rounded to fp16 first, exactly as it is when stored and rotated by esm_rope_kernel
                             const float a = (float)(half_t)(e < 4 ? l0[e] : l1[e - 4]) * qs, b = (float)(half_t)(e < 4 ? h0[e] : h1[e - 4]) * qs;
                             const float cc = csv[2 * e], sn = csv[2 * e + 1];
-                            olo[e] = (half_t)(a * cc - b * sn);
-                            ohi[e] = (half_t)(b * cc + a * sn);
+                            float rl, rh;
+                            rotate_pair(a, b, cc, sn, rl, rh);
+                            olo[e] = (half_t)rl;
+                            ohi[e] = (half_t)rh;
                         }
                         if (m < p.M) {
                             half_t *dst = reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c;

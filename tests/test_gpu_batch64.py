@@ -171,6 +171,58 @@ def test_b64_decode_step_agrees_with_prefill_of_longer_prompt(big64):
     assert int(decisive.sum()) >= 48
 
 
+@pytest.mark.parametrize("B,T", [(64, 514), (40, 130), (7, 1026), (3, 514)])
+def test_fused_rotary_epilogue_is_the_standalone_kernel(big64, B, T):
+    """Row E2 at the batch-64 shape: the ESM rotary applied in the QKV projection's epilogue (gemm_pp_kernel) is bit-identical
+    to the stand-alone rotary kernel run on the stored projection, and both agree with rotary(fp64 projection) computed here
+    (q scaled by head_dim^-0.5 before the rotation, position = row % T, pairs (d, d + 32): modeling_esm.py:374 / rotary
+    embedding).  The last case has too few tiles for the big kernel: both calls then take the stand-alone kernel."""
+    import ctypes as C
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model = big64
+    dev = model.device if hasattr(model, "device") else torch.device("cuda:0")
+    D, K, heads, hd = cfg.enc_dim, cfg.enc_dim, cfg.enc_heads, cfg.enc_dim // cfg.enc_heads
+    M = B * T
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+    W = (torch.randn(3 * D, K, generator=g) / K ** 0.5).half()
+    bias = (torch.randn(3 * D, generator=g) * 0.1).to(dev)
+    dW = tile_weight(W.to(dev))
+    outs, fused = [], []
+    for allow in (1, 0):
+        out = torch.empty(M, 3 * D, dtype=torch.float16, device=dev)
+        f = C.c_int32(-1)
+        _cabi.check(_cabi.lib().opus_debug_gemm_rope(model._ctx, A.data_ptr(), dW.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                     M, D, K, T, heads, allow, C.byref(f), None))
+        torch.cuda.synchronize()
+        outs.append(out)
+        fused.append(f.value)
+    big = -(-M // 256) * -(-3 * D // 256) >= 128                # enough 256 x 256 tiles for gemm_pp_kernel (launch_tile_e)
+    assert fused[1] == 0 and fused[0] == int(big), fused
+    tiles = -(-M // 256) * -(-3 * D // 256)
+    tail_split = tiles > 256 and 0 < tiles % 256 <= 128         # the plain launch cuts its last round into k-parts (another
+    if tail_split:                                              # summation order in those tiles); the fused one does not
+        d = (outs[0].float() - outs[1].float()).abs()
+        assert float(d.max()) <= 2e-3 * float(outs[1].float().abs().max()) and int((d > 0).sum()) < 2e-3 * d.numel()
+    else:
+        assert torch.equal(outs[0], outs[1])
+    # reference on a sample of rows (fp64 projection, rounded to fp16 as both paths store / hold it, then the rotation)
+    rows = torch.tensor([0, 1, T - 1, T, M // 2 + 3, M - 1])
+    proj = (A[rows].double().cpu() @ W.double().T + bias.double().cpu()).half().double()
+    ref = proj.clone()
+    pos = (rows % T).double()
+    inv = 1.0 / (cfg.enc_rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float64) / hd))
+    ang = pos[:, None] * inv[None, :]
+    cos, sin = torch.cos(ang.float()).double(), torch.sin(ang.float()).double()
+    for part, scale in ((0, hd ** -0.5), (1, 1.0)):
+        x = proj[:, part * D:(part + 1) * D].view(len(rows), heads, hd) * scale
+        a, b = x[..., :hd // 2], x[..., hd // 2:]
+        ref[:, part * D:(part + 1) * D] = torch.cat([a * cos[:, None] - b * sin[:, None], b * cos[:, None] + a * sin[:, None]], -1).view(len(rows), D)
+    err = (outs[0][rows.to(dev)].double().cpu() - ref).abs().max().item()
+    assert err <= 3e-3 * ref.abs().max().item(), err            # fp16 rounding of a 1280-term projection's neighbours
+
+
 @pytest.mark.parametrize("M,N2,epi", [(8, 28672, 2), (32, 28672, 2), (64, 28672, 2), (96, 28672, 2), (64, 16384, 0), (20, 32064, 0)])
 def test_rowscale_rmsnorm_fusion_vs_fp64(big64, M, N2, epi):
     """The fused pair of api.cpp prefill / decode_step (wo split-K reduce writes fp16(x) + per-block sums of squares, the wide
