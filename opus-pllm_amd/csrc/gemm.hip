@@ -100,9 +100,10 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
         h8 wlA[U], whA[U], wlB[U], whB[U];
         // rotated start of every wave's k-range (see gemm_wide_kernel: panel stride = 128 KB at K = 4096 puts the whole chip on
         // the same memory channels).  Single-GEMM timings are within noise either way; the batch-1 step as a whole is 3.5 %
-        // faster (109.8 -> 106.0 ms, two alternating runs each).
+        // faster (109.8 -> 106.0 ms, two alternating runs each).  The start depends on the wave only: of the multipliers
+        // tried on the step, (workgroup, wave) = (0, 3) was best (104.1 ms), (5, 3) 105.4-106.0, (1, 0) no better than none.
         const int nck = c1 - c0;
-        const int rot = (!p.no_rot && nck >= 2) ? (int)((blockIdx.x * 5u + wave * 3u) % (unsigned)nck) : 0;
+        const int rot = (!p.no_rot && nck >= 2) ? (int)((wave * 3u) % (unsigned)nck) : 0;
         auto phys = [&](int c) { const int q = c + rot; return q < c1 ? q : q - nck; };
         auto wload = [&](h8 (&wl)[U], h8 (&wh)[U], int c) {
 #pragma unroll
