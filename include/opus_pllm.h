@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 4
+#define OPUS_ABI_VERSION 5
 
 enum opus_status {
     OPUS_OK = 0,
@@ -171,8 +171,17 @@ int opus_debug_gemm(opus_ctx *ctx, const void *d_A, const void *d_W, const float
 /* Same with the fused RMSNorm prologue: A is fp32 [M,K], C = epi(rmsnorm(A) W^T) (norm weight folded in W). */
 int opus_debug_gemm_norm(opus_ctx *ctx, const float *d_A, const void *d_W, void *d_C, int32_t M, int32_t N, int32_t K,
                          int32_t epi, int32_t out_f32, float eps, void *stream);
-/* The row-scale RMSNorm fusion as the decoder issues it (api.cpp prefill / decode_step): X <- X + A W1^T through a
- * split-K GEMM whose reduce also writes fp16(X) and per-256-column sums of squares, then C = epi(rmsnorm(X) W2^T) with
+/* The QKV projection of the batched decode step as decode_step issues it (5..64 rows, narrow output, k-parts leave raw fp32
+ * slabs that the attention kernel sums): d_slabs fp32 [*ks][M][N] receives them, *ks (HOST) their number; *ks = 1: the launch
+ * wrote a finished output instead and nothing is copied. */
+int opus_debug_gemm_slabs(opus_ctx *ctx, const void *d_A, const void *d_W, float *d_slabs, int32_t M, int32_t N, int32_t K,
+                          int32_t *ks, void *stream);
+/* Process-wide tuning knob of the benchmarks / parity tests (no reference counterpart): "no_stream" = 1 routes the narrow
+ * GEMMs of the batched decode step through the round-2 split-K kernels instead of gemm_stream_kernel; "pp_gm" = tile rows
+ * per rasterisation group of the big tiled GEMM; "debug_a_tiled" = 1: opus_debug_gemm takes A in fragment order; "misc0".."misc7" scratch.  ctx (may be NULL) drops its captured decode graph. */
+int opus_debug_knob(opus_ctx *ctx, const char *name, int32_t value);
+/* The row-scale RMSNorm fusion as the decoder issues it (api.cpp prefill / decode_step): X <- X + A W1^T through a GEMM
+ * (gemm_stream_kernel at 5..64 rows, else a split-K GEMM) whose epilogue / reduce also writes fp16(X) and per-block sums of squares, then C = epi(rmsnorm(X) W2^T) with
  * the rows scaled inside the consumer GEMM.  A fp16 [M,K1], W1 [N1,K1] and W2 [N2,N1] panel-tiled, X fp32 [M,N1] in/out,
  * C fp16 [M, N2 or N2/2]; *fused (HOST) = 1 when the fused kernels ran. */
 int opus_debug_gemm_rowscale(opus_ctx *ctx, const void *d_A, const void *d_W1, float *d_X, const void *d_W2, void *d_C,

@@ -13,7 +13,7 @@ from .config import OpusConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libopus_pllm.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OPUS_F16, OPUS_F32, OPUS_I32, OPUS_I64, OPUS_U8 = 0, 1, 2, 3, 4
 
@@ -83,6 +83,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "opus_timing_names": (C.c_int, [C.c_char_p, C.c_int32]),
     "opus_last_logits": (C.c_int, [_P, _P, C.c_int32, _P]),
+    "opus_debug_gemm_slabs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P]),
+    "opus_debug_knob": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "opus_debug_gemm_rowscale": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_float, C.POINTER(C.c_int32), _P]),
 }

@@ -111,9 +111,14 @@ struct opus_ctx {
     float rq_rope_qscale = 1.0f;
     // one-shot requests for the next gemm(): route a narrow output through the wide kernel / leave raw k-part slabs
     int rq_force_wide = 0, rq_slab_only = 0, rq_ks = 1;
+    // one-shot: the next gemm() reads A / writes the fp16 copy of its output in fragment order (GemmParams::a_tiled / xh_tiled)
+    int rq_a_tiled = 0, rq_xh_tiled = 0;
+    bool xln_tiled = false;              // d_xln currently holds fp16(x) in fragment order
     const float *xh_src = nullptr;       // fp32 buffer whose fp16 copy + sum-of-squares partials are valid
     bool use_row_scale = false;          // one-shot: the next gemm() multiplies its rows by the rstd from d_ssq
     float *d_ssq = nullptr;
+    int64_t ssq_cap = 0;                 // floats in d_ssq
+    int ssq_nblk = 0;                    // blocks per row the last producer wrote (N / 256: split-K reduce, embedding; N / 16: gemm_stream)
     float row_eps = 0.f;
     // timing
     bool timing = false;
@@ -156,7 +161,10 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->p_y = k.take<half_t>(PR * (size_t)(g.has_protein_projector ? g.proj_dim : g.enc_dim));
     c->p_z[0] = k.take<half_t>(PR * SW);
     c->p_z[1] = k.take<half_t>(PR * SW);
-    const size_t Md = B * g.max_prompt;
+    // rows of the decoder activation buffers: whole 16-row tiles, so that the fragment-ordered layout of the batched decode
+    // step (tiled_off) fits for every batch size
+    const size_t B16 = (B + 15) & ~(size_t)15;
+    const size_t Md = B * g.max_prompt > B16 ? B * g.max_prompt : B16;
     const size_t QKV = (size_t)(g.dec_heads + 2 * g.dec_kv_heads) * g.dec_head_dim;
     const size_t QD = (size_t)g.dec_heads * g.dec_head_dim;
     c->d_x = k.take<float>(Md * H);
@@ -165,7 +173,7 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_ctx = k.take<half_t>(Md * QD);
     c->d_act = k.take<half_t>(Md * g.dec_ffn);
     c->d_xl = k.take<float>(B * H);
-    c->d_xln = k.take<half_t>(B * H);
+    c->d_xln = k.take<half_t>(B16 * H);
     c->d_logits = k.take<float>(B * (size_t)g.dec_vocab);
     const size_t ctx = (size_t)g.max_prompt + g.max_new_tokens;
     c->cache_sh = (int64_t)ctx * g.dec_head_dim;
@@ -194,7 +202,9 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->gemm_ws_bytes = 64ll << 20;   // split-K slabs of the tile GEMM
     c->gemm_ws = k.take<float>((size_t)c->gemm_ws_bytes / sizeof(float));
     c->d_pidx = k.take<int32_t>(64 * B);
-    c->d_ssq = k.take<float>(128 * 32);
+    // per-row sums of squares of the row-scale RMSNorm fusion: up to 128 rows x one float per 16 columns of the residual stream
+    c->ssq_cap = 128 * (int64_t)(g.dec_dim / 16 > 32 ? g.dec_dim / 16 : 32);
+    c->d_ssq = k.take<float>((size_t)c->ssq_cap);
     *total = k.off;
 }
 
@@ -463,7 +473,7 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     p.A = A; p.Af = Af; p.norm_eps = eps; p.lda = lda; p.W = W; p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.residual = residual; p.ldr = ldc; p.C = C; p.ldc = ldc; p.out_f32 = out_f32; p.epi = epi;
     p.ws = c->gemm_ws; p.ws_bytes = c->gemm_ws_bytes;
-    p.xh_out = c->rq_xh; p.ssq_out = c->d_ssq; p.fused_done = &c->rq_done;
+    p.xh_out = c->rq_xh; p.ssq_out = c->d_ssq; p.fused_done = &c->rq_done; p.ssq_cap = c->ssq_cap; p.nblk_out = &c->ssq_nblk;
     c->rq_done = 0;
     c->rq_xh = nullptr;                  // one-shot
     p.rope_cs = c->rq_rope_cs; p.rope_T = c->rq_rope_T; p.rope_cols = c->rq_rope_cols; p.rope_qcols = c->rq_rope_qcols;
@@ -471,10 +481,12 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     c->rq_rope_done = 0;
     c->rq_rope_cs = nullptr;             // one-shot
     p.row_ssq = nullptr; p.row_nblk = 0;
-    if (c->use_row_scale) { p.row_ssq = c->d_ssq; p.row_nblk = K >> 8; p.norm_eps = c->row_eps; c->use_row_scale = false; }
+    if (c->use_row_scale) { p.row_ssq = c->d_ssq; p.row_nblk = c->ssq_nblk; p.norm_eps = c->row_eps; c->use_row_scale = false; }
     c->rq_ks = 1;
     p.force_wide = c->rq_force_wide; p.slab_only = c->rq_slab_only; p.ks_out = &c->rq_ks;
     c->rq_force_wide = c->rq_slab_only = 0;
+    p.a_tiled = c->rq_a_tiled; p.xh_tiled = c->rq_xh_tiled;
+    c->rq_a_tiled = c->rq_xh_tiled = 0;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     // algorithmic bytes: the weights once + activations in + result out (+ the residual read)
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
@@ -730,7 +742,7 @@ static int lm_head(opus_ctx *c, hipStream_t s, int B) {
 // decode-step attention of layer l over the projection output in d_qkv (rows of the last prefill, T prompt positions)
 // (slab_ks > 0: the QKV GEMM left slab_ks raw k-part slabs in the GEMM workspace and the sums of squares of its input rows in
 // d_ssq: summed, scaled and biased by the attention kernel itself)
-static int attn_decode(opus_ctx *c, hipStream_t s, int l, int B, int T, int slab_ks = 0, const float *bias = nullptr) {
+static int attn_decode(opus_ctx *c, hipStream_t s, int l, int B, int T, int slab_ks = 0, const float *bias = nullptr, int out_tiled = 0) {
     const opus_config &g = c->cfg;
     AttnDecodeParams a;
     a.qkv = c->d_qkv; a.slabs = nullptr; a.ks = 0; a.slab_stride = 0; a.row_ssq = nullptr; a.row_nblk = 0; a.eps = 0.f; a.K = 0;
@@ -738,11 +750,12 @@ static int attn_decode(opus_ctx *c, hipStream_t s, int l, int B, int T, int slab
     if (slab_ks > 0) {
         const int64_t QKVd = (int64_t)(g.dec_heads + 2 * g.dec_kv_heads) * g.dec_head_dim;
         a.qkv = nullptr; a.slabs = c->gemm_ws; a.ks = slab_ks; a.slab_stride = (int64_t)B * QKVd;
-        a.row_ssq = c->d_ssq; a.row_nblk = g.dec_dim >> 8; a.eps = g.dec_rms_eps; a.K = g.dec_dim; a.bias = bias;
+        a.row_ssq = c->d_ssq; a.row_nblk = c->ssq_nblk; a.eps = g.dec_rms_eps; a.K = g.dec_dim; a.bias = bias;
     }
     a.cs = c->cs_dec; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = T; a.nh = g.dec_heads; a.nkv = g.dec_kv_heads;
     a.kc = c->kc + l * c->cache_sl; a.vc = c->vc + l * c->cache_sl; a.cache_sb = c->cache_sb; a.cache_sh = c->cache_sh;
     a.ctx_cap = g.max_prompt + g.max_new_tokens; a.scale = 1.0f / sqrtf((float)g.dec_head_dim); a.out = c->d_ctx;
+    a.out_tiled = out_tiled;
     // algorithmic bytes: the rows' K / V history once (+ the new token's q, k, v and the output)
     const double bytes = 4.0 * B * g.dec_kv_heads * g.dec_head_dim * (T + 1) + 2.0 * B * (2.0 * g.dec_heads + 2.0 * g.dec_kv_heads) * g.dec_head_dim;
     KL(KC_ATTN_DECODE, bytes, launch_attn_decode(a, B, g.dec_head_dim, s));
@@ -887,9 +900,16 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     // layer's QKV GEMM can take the row-scale RMSNorm form like every later one (whose producer is the previous down GEMM)
     const bool rowscale = g.dec_arch == 0 && fuse_rows() && B > SKINNY_MAX_M && B <= MID_MAX_M && (H & 255) == 0 &&
                           !(stack_enabled() && !g.dec_qkv_bias && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap));
+    // Fragment-ordered fp16 activations for the GEMMs that gemm_stream_kernel will take (gemm_stream.hip "Activation layout"):
+    // the producer of each such matrix is told to write that layout - fp16(x) for the QKV projection (embedding kernel for
+    // layer 0, the down projection's epilogue / reduce afterwards) and the attention output for the wo projection.
+    const bool qkv_tiled = rowscale && gemm_stream_would(B, QKV, H, 1, 1, 1, c->gemm_ws_bytes);
+    const bool wo_tiled = rowscale && gemm_stream_would(B, H, QD, 0, 1, 0, c->gemm_ws_bytes);
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, rowscale ? c->d_xln : nullptr,
-                                                  rowscale ? c->d_ssq : nullptr, s));
+                                                  rowscale ? c->d_ssq : nullptr, qkv_tiled ? 1 : 0, s));
+    c->xln_tiled = qkv_tiled;
     c->xh_src = rowscale ? c->d_xl : nullptr;
+    if (rowscale) c->ssq_nblk = H >> 8;
     if (g.dec_arch == 1) return decode_step_opt(c, s);
     if (stack_enabled() && !g.dec_qkv_bias && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap)) {
         c->stack_used = true;
@@ -926,19 +946,24 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
             c->rq_slab_only = 1;
             c->use_row_scale = true;
             c->row_eps = g.dec_rms_eps;
+            c->rq_a_tiled = c->xln_tiled ? 1 : 0;
             OPC(gemm(c, s, c->d_xln, H, L.wqkv, B, QKV, H, L.bqkv, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
-            OPC(attn_decode(c, s, l, B, T, c->rq_ks > 1 ? c->rq_ks : 0, L.bqkv));
+            OPC(attn_decode(c, s, l, B, T, c->rq_ks > 1 ? c->rq_ks : 0, L.bqkv, wo_tiled ? 1 : 0));
         } else {
             OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wqkv, B, QKV, H, EPI_NONE, c->d_qkv, QKV, 0, L.bqkv));
-            OPC(attn_decode(c, s, l, B, T));
+            OPC(attn_decode(c, s, l, B, T, 0, nullptr, wo_tiled ? 1 : 0));
         }
-        if (fuse_rows() && B <= 96) c->rq_xh = c->d_xln;
+        c->xln_tiled = false;
+        if (fuse_rows() && B <= 96) c->rq_xh = c->d_xln;                 // (row-major: the gate/up kernel stages it by LDS-DMA)
+        c->rq_a_tiled = wo_tiled ? 1 : 0;
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, B, H, QD, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
         c->xh_src = c->rq_done ? c->d_xl : nullptr;
         OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wgu, B, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
-        if (fuse_rows() && B <= 96) c->rq_xh = c->d_xln;
+        const bool next_tiled = qkv_tiled && l + 1 < g.dec_layers;      // (the last layer's fp16(x) feeds lm_head: row-major)
+        if (fuse_rows() && B <= 96) { c->rq_xh = c->d_xln; c->rq_xh_tiled = next_tiled ? 1 : 0; }
         OPC(gemm(c, s, c->d_act, F, L.wd, B, H, F, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
         c->xh_src = c->rq_done ? c->d_xl : nullptr;
+        c->xln_tiled = c->rq_done && next_tiled;
     }
     OPC(lm_head(c, s, B));
     KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
@@ -1125,6 +1150,7 @@ extern "C" int opus_debug_gemm(opus_ctx *c, const void *A, const void *W, const 
     if (epi < 0 || epi > 2 || (epi == 2 && N % 32)) return fail(OPUS_EBADARG, "debug_gemm: epilogue");
     HIPC(hipSetDevice(c->device));
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
+    c->rq_a_tiled = g_knobs.debug_a_tiled;     // (tests: A handed over in fragment order, ceil(M / 16) * 16 rows)
     return gemm(c, (hipStream_t)stream, (const half_t *)A, K, (const half_t *)W, M, N, K, bias, epi, residual, Cp, nout,
                 out_f32);
 }
@@ -1185,6 +1211,28 @@ extern "C" int opus_debug_gemm_rowscale(opus_ctx *c, const void *A, const void *
     return gemm_norm(c, s, X, eps, c->d_xn, (const half_t *)W2, M, N2, N1, epi, Cp, nout, 0);
 }
 
+// The QKV projection of the batched decode step exactly as decode_step() issues it (narrow output routed through the
+// k-part kernels, raw slabs left for the attention kernel): d_slabs fp32 [*ks][M][N] receives the slabs, *ks (HOST) their
+// number; *ks = 1 means the launch wrote a finished fp16 output instead (nothing is copied).
+extern "C" int opus_debug_gemm_slabs(opus_ctx *c, const void *A, const void *W, float *d_slabs, int32_t M, int32_t N, int32_t K,
+                                     int32_t *ks, void *stream) {
+    if (!c || !A || !W || !ks) return fail(OPUS_EBADARG, "debug_gemm_slabs: null pointer");   // (d_slabs may be NULL: timing runs)
+    if (M < 1 || N < 16 || K < 64 || K % 64) return fail(OPUS_ESHAPE, "debug_gemm_slabs: shape");
+    const opus_config &g = c->cfg;
+    const int64_t QKVd = (int64_t)(g.dec_heads + 2 * g.dec_kv_heads) * g.dec_head_dim;
+    if ((int64_t)M * N > (int64_t)g.max_batch * g.max_prompt * QKVd) return fail(OPUS_ESHAPE, "debug_gemm_slabs: M * N exceeds the scratch");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    c->rq_force_wide = 1;
+    c->rq_slab_only = 1;
+    c->rq_a_tiled = g_knobs.debug_a_tiled;
+    OPC(gemm(c, s, (const half_t *)A, K, (const half_t *)W, M, N, K, nullptr, EPI_NONE, nullptr, c->d_qkv, N, 0));
+    *ks = c->rq_ks;
+    if (c->rq_ks > 1 && d_slabs)
+        HIPC(hipMemcpyAsync(d_slabs, c->gemm_ws, (size_t)c->rq_ks * M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return OPUS_OK;
+}
+
 // fp32 logits [B, dec_vocab] of the most recent prefill / decode step of this context (the optional logits gather of
 // SURVEY 8e; also what a caller needs to apply its own logits processors).
 extern "C" int opus_last_logits(opus_ctx *c, float *d_out, int32_t B, void *stream) {
@@ -1213,6 +1261,21 @@ extern "C" int opus_debug_attention(opus_ctx *c, const void *Q, const void *K, c
     a.causal = causal; a.scale = scale;
     KLF(KC_ATTN_PREFILL, 2.0 * B * T * hd * (2.0 * heads + 2.0 * kvh), (causal ? 2.0 : 4.0) * B * (double)T * T * heads * hd,
         launch_attn_prefill(a, s));
+    return OPUS_OK;
+}
+
+// Run-time tuning knobs (A/B aids of the benchmarks and tests; process-wide): "no_stream", "pp_gm", "misc0" .. "misc7".
+extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
+    if (!name) return fail(OPUS_EBADARG, "debug_knob: null name");
+    if (c) {   // a captured decode graph replays the kernels it was recorded with
+        if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        c->g_B = -1;
+    }
+    if (!strcmp(name, "no_stream")) g_knobs.no_stream = value;
+    else if (!strcmp(name, "debug_a_tiled")) g_knobs.debug_a_tiled = value;
+    else if (!strcmp(name, "pp_gm")) { if (value < 1 || value > 64) return fail(OPUS_EBADARG, "pp_gm out of range"); g_knobs.pp_gm = value; }
+    else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '7' && !name[5]) g_knobs.misc[name[4] - '0'] = value;
+    else return fail(OPUS_EBADARG, "debug_knob: unknown knob '%s'", name);
     return OPUS_OK;
 }
 

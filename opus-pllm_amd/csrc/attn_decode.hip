@@ -92,9 +92,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     float rstd = 1.0f;
     if (p.row_ssq) {
         float q = 0.f;
-        for (int j0 = 0; j0 < p.row_nblk; j0 += 64) {
-            const int j = j0 + lane;
-            q += j < p.row_nblk ? p.row_ssq[b * p.row_nblk + j] : 0.f;
+        for (int j0 = 0; j0 < p.row_nblk; j0 += 256) {            // (16-column blocks from gemm_stream_kernel: 256 of them at H = 4096)
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 64 * u + lane;
+                t[u] = p.row_ssq[(int64_t)b * p.row_nblk + (j < p.row_nblk ? j : p.row_nblk - 1)];
+                t[u] = j < p.row_nblk ? t[u] : 0.f;
+            }
+            q += (t[0] + t[1]) + (t[2] + t[3]);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
@@ -319,7 +325,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             num += f * s;
             den += f * stats[(w * GP + h) * 2 + 1];
         }
-        p.out[(int64_t)b * p.nh * HD + (int64_t)(h0 + h) * HD + d] = (half_t)(num / den);
+        const int kcol = (h0 + h) * HD + d;             // column of the [B, nh HD] context matrix
+        p.out[p.out_tiled ? tiled_off(b, kcol, p.nh * HD) : (int64_t)b * p.nh * HD + kcol] = (half_t)(num / den);
     }
 }
 

@@ -66,6 +66,12 @@ __device__ __forceinline__ void rotate_pair(float a, float b, float c, float sn,
     asm volatile("" : "+v"(lo), "+v"(hi));
 }
 
+// offset (in elements) of element (row, k) of a fragment-ordered [rows, K] fp16 matrix: 16-row x 64-k blocks of 2 KB in MFMA
+// operand order [k-step][lane = 16 ((k % 32) / 8) + row % 16][8] - the panel-tiled weight layout with rows for output columns
+__host__ __device__ __forceinline__ int64_t tiled_off(int row, int k, int K) {
+    return ((int64_t)(row >> 4) * (K >> 6) + (k >> 6)) * 1024 + ((k & 63) >> 5) * 512 + ((((k & 31) >> 3) << 4) + (row & 15)) * 8 + (k & 7);
+}
+
 struct GemmParams {
     const half_t *A;        // fp16 activations [M,K] (row-major, lda), or
     const float *Af;        // fp32 residual stream [M,K]: fused RMSNorm (skinny kernel only), else nullptr
@@ -86,11 +92,16 @@ struct GemmParams {
     //  producer side - the flat split-K reduce (EPI_NONE, fp32 output, N % 256 == 0) also writes the row as fp16 to xh_out
     //  and the sum of squares of each 256-column block to ssq_out[m * N/256 + j], then sets *fused_done;
     //  consumer side - gemm_wide_kernel multiplies row m of its result by rsqrt(sum_j row_ssq[m * row_nblk + j] / K + norm_eps).
+    //  The blocks are 256 columns wide when a split-K reduce (or the embedding kernel) produced them and 16 columns wide when
+    //  gemm_stream_kernel did: *nblk_out (HOST) receives the number of blocks per row the producer wrote (at most ssq_cap floats
+    //  in all), the consumer gets it back as row_nblk.
     half_t *xh_out;
     float *ssq_out;
     int *fused_done;
     const float *row_ssq;
     int row_nblk;
+    int64_t ssq_cap = 0;
+    int *nblk_out = nullptr;
     // slab_only: when the launch splits K over workgroups, leave the raw fp32 k-part slabs in ws ([ks][M][N], no epilogue) and
     // report their number in *ks_out instead of launching the reduce - the consumer (attn_decode_kernel) sums them, applies the
     // row scale and the bias itself; *ks_out = 1 means the kernel wrote the finished output as usual.
@@ -105,6 +116,10 @@ struct GemmParams {
     int rope_T = 0, rope_cols = 0, rope_qcols = 0;
     float rope_qscale = 1.0f;
     int *rope_done = nullptr;
+    // Fragment-ordered ("tiled") activation matrices of the batched decode step (gemm_stream.hip, "Activation layout"):
+    // element (row, k) of an [rows, K] matrix at tiled_off(row, k, K).  a_tiled: A is stored that way (gemm_stream_kernel only);
+    // xh_tiled / c_tiled: write xh_out / the fp16 output C that way (for a consumer that will read it with a_tiled).
+    int a_tiled = 0, xh_tiled = 0, c_tiled = 0;
     int no_rot = 0;               // A/B aid (OPUS_NO_KROT): weight-streaming kernels walk k from chunk 0 in every workgroup
     long long *trace = nullptr;   // tuning aid (OPUS_PP_TRACE): gemm_pp_kernel writes 4 wall-clock stamps per workgroup
 };
@@ -124,6 +139,52 @@ struct AttnParams {
 };
 
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass);
+// gemm_stream.hip: one-launch weight streaming for narrow outputs at 5..64 rows (K cut over the waves of a workgroup)
+bool gemm_stream_ok(const GemmParams &p);
+bool gemm_stream_would(int M, int N, int K, int slab_only, int a_tiled, int row_scale, int64_t ws_bytes);
+hipError_t launch_gemm_stream(const GemmParams &p, hipStream_t s);
+// Run-time tuning knobs (A/B aids; opus_debug_knob sets them, environment variables give the defaults)
+struct Knobs {
+    int no_stream = 0;      // 1: narrow decode GEMMs take the round-2 kernels (gemm_wide / gemm_ring / gemm_mid + reduce)
+    int debug_a_tiled = 0;  // 1: opus_debug_gemm takes A in fragment order (GemmParams::a_tiled)
+    int pp_gm = 8;          // tile-rows per group of the gemm_pp / gemm_ring rasterisation
+    int misc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // scratch knobs for experiments
+};
+extern Knobs g_knobs;
+// rstd[r] = rsqrt(sum_j ssq[r * nblk + j] / K + eps) for rows r < rows, computed by the whole workgroup (NWAVES waves) into
+// LDS `out`: every load of a wave's rows is requested before the first sum (one round trip, not nblk / 4)
+template <int NWAVES, int ROWS>
+__device__ __forceinline__ void block_row_rstd(const float *__restrict__ ssq, int M, int nblk, float inv_k, float eps, float *out,
+                                               int wave, int lane) {
+    constexpr int RW = (ROWS + NWAVES - 1) / NWAVES;
+    float part[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) part[r] = 0.f;
+    for (int j0 = 0; j0 < nblk; j0 += 256) {
+        float t[RW][4];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            int row = wave + NWAVES * r;
+            row = row < M ? row : M - 1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 64 * u + lane;
+                t[r][u] = ssq[(int64_t)row * nblk + (j < nblk ? j : nblk - 1)];
+                t[r][u] = j < nblk ? t[r][u] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) part[r] += (t[r][0] + t[r][1]) + (t[r][2] + t[r][3]);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float q = part[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const int row = wave + NWAVES * r;
+        if (lane == 0 && row < ROWS) out[row] = rsqrtf(q * inv_k + eps);
+    }
+}
 bool gemm_goes_wide(int M, int N);   // would launch_gemm route an fp16-A GEMM of this shape to gemm_wide_kernel?
 hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s);
 
@@ -148,7 +209,7 @@ hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s);
 // x[b,:] = fp32(emb[tok[b]]); optionally also the fp16 copy xh and the per-256-column sums of squares ssq[b][H/256] (the
 // producer side of the row-scale RMSNorm fusion, GemmParams::row_ssq)
 hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
-                               hipStream_t s);
+                               int xh_tiled, hipStream_t s);
 hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, const int32_t *step, int t0, int B, int Tq,
                           int H, int max_idx, hipStream_t s);
 hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s);
@@ -194,6 +255,7 @@ struct AttnDecodeParams {
     int ctx_cap;
     float scale;
     half_t *out;                // [B][nh hd]
+    int out_tiled = 0;          // write `out` in fragment order (tiled_off) for a GemmParams::a_tiled consumer
 };
 hipError_t launch_attn_decode(const AttnDecodeParams &p, int B, int hd, hipStream_t s);
 

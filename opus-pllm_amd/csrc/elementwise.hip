@@ -181,7 +181,7 @@ hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, co
 // RMSNorm fusion of the first layer's QKV GEMM consumes (GemmParams::row_ssq).
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__restrict__ tok, const half_t *__restrict__ emb,
                                                            int H, int V, float *__restrict__ x, half_t *__restrict__ xh,
-                                                           float *__restrict__ ssq) {
+                                                           float *__restrict__ ssq, int xh_tiled) {
     const int b = blockIdx.x;
     int id = tok[b];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__rest
         o[0] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
         o[1] = make_float4((float)e[4], (float)e[5], (float)e[6], (float)e[7]);
         if (xh) {
-            *reinterpret_cast<h8 *>(xh + (int64_t)b * H + c * 8) = e;
+            *reinterpret_cast<h8 *>(xh + (xh_tiled ? tiled_off(b, c * 8, H) : (int64_t)b * H + c * 8)) = e;
             float q = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) q += (float)e[j] * (float)e[j];
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__rest
     }
 }
 hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
-                               hipStream_t s) {
+                               int xh_tiled, hipStream_t s) {
     if (xh && (H & 255)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x, xh, ssq);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x, xh, ssq, xh_tiled);
     return hipGetLastError();
 }
 

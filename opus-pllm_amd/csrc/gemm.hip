@@ -26,6 +26,7 @@
 namespace opus {
 
 thread_local LaunchEvents *tl_launch_ev = nullptr;
+Knobs g_knobs;
 
 hipError_t ensure_dyn_lds(const void *fn, size_t bytes) {
     static std::mutex mu;
@@ -1455,6 +1456,7 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
 
 template <int EPI>
 static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
+    if (p_in.row_ssq) return hipErrorInvalidValue;                    // no row scale in this kernel's epilogue
     GemmParams p = p_in;
     const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_pp_kernel<EPI>), 8 * 16384);
@@ -1529,9 +1531,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
         for (int k = 0; k < ksplit; ++k) q += p.ws[ksplit * slab + (int64_t)k * p.M + m];
         rstd = rsqrtf(q / (float)p.K + p.norm_eps);
     } else if (p.row_ssq) {   // row-scale fusion: the producer of A left per-block sums of squares of its rows
-        float q = 0.f;
-        for (int j = 0; j < p.row_nblk; ++j) q += p.row_ssq[m * p.row_nblk + j];
-        rstd = rsqrtf(q / (float)p.K + p.norm_eps);
+        const float *src = p.row_ssq + (int64_t)m * p.row_nblk;
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= p.row_nblk; j += 4) { q0 += src[j]; q1 += src[j + 1]; q2 += src[j + 2]; q3 += src[j + 3]; }
+        for (; j < p.row_nblk; ++j) q0 += src[j];
+        rstd = rsqrtf(((q0 + q1) + (q2 + q3)) / (float)p.K + p.norm_eps);
     }
     float v;
     if (EPI == EPI_SILU_GU16) {
@@ -1574,7 +1579,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ks
     if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + no] = v;
     else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + no] = (half_t)v;
     if (EPI == EPI_NONE && p.xh_out) {   // (host guarantees N % 256 == 0: the workgroup lies inside one row, no early return above)
-        p.xh_out[(int64_t)m * p.N + no] = (half_t)v;
+        p.xh_out[p.xh_tiled ? tiled_off(m, no, p.N) : (int64_t)m * p.N + no] = (half_t)v;
         __shared__ float part[4];
         float q = v * v;
 #pragma unroll
@@ -1599,9 +1604,12 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(GemmParams p, int k
         for (int k = 0; k < ksplit; ++k) q += p.ws[ksplit * slab + (int64_t)k * p.M + m];
         rstd = rsqrtf(q / (float)p.K + p.norm_eps);
     } else if (p.row_ssq) {
-        float q = 0.f;
-        for (int j = 0; j < p.row_nblk; ++j) q += p.row_ssq[m * p.row_nblk + j];
-        rstd = rsqrtf(q / (float)p.K + p.norm_eps);
+        const float *src = p.row_ssq + (int64_t)m * p.row_nblk;
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= p.row_nblk; j += 4) { q0 += src[j]; q1 += src[j + 1]; q2 += src[j + 2]; q3 += src[j + 3]; }
+        for (; j < p.row_nblk; ++j) q0 += src[j];
+        rstd = rsqrtf(((q0 + q1) + (q2 + q3)) / (float)p.K + p.norm_eps);
     }
     // every load of the kernel is requested before the first sum (a `load, add` loop over the slabs is ksplit dependent round
     // trips: at 8 slabs that chain, not the 10 MB moved, was the kernel's 5 us); slabs are still added in index order
@@ -1633,7 +1641,7 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(GemmParams p, int k
     if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + no) = make_float4(v[0], v[1], v[2], v[3]);
     else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + no) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
     if (p.xh_out) {
-        *reinterpret_cast<h4 *>(p.xh_out + (int64_t)m * p.N + no) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<h4 *>(p.xh_out + (p.xh_tiled ? tiled_off(m, no, p.N) : (int64_t)m * p.N + no)) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
@@ -1645,8 +1653,13 @@ template <int EPI>
 static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s) {
     const int nout = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
     GemmParams q = p;
-    if (EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 && !p.Af && (p.N & 255) == 0) *p.fused_done = 1;
-    else q.xh_out = nullptr;
+    if (EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 && !p.Af && (p.N & 255) == 0 &&
+        (int64_t)p.M * (p.N >> 8) <= p.ssq_cap) {
+        *p.fused_done = 1;
+        if (p.nblk_out) *p.nblk_out = p.N >> 8;
+    } else {
+        q.xh_out = nullptr;
+    }
     if (tl_launch_ev) tl_launch_ev->aux_bytes = 4.0 * ks * p.M * p.N + (double)p.M * nout * ((p.out_f32 ? 4 : 2) + (p.residual ? 4 : 0));
     if (EPI == EPI_NONE && (p.N & 255) == 0 && ((p.ldc | p.ldr) & 3) == 0)
         OPUS_LAUNCH(KC_REDUCE, splitk_reduce4_kernel, dim3(cdiv((int64_t)p.M * p.N, 1024)), dim3(256), 0, s, q, ks);
@@ -1736,23 +1749,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
         aoff[i] = r * 128 + ((g ^ ((r >> 1) & 7)) << 4);             // second k-step: ^ (4 << 4) on the chunk index
     }
 
-    // row sums of squares for the fused RMSNorm (GemmParams::row_ssq): requested up front, used in the epilogue
-    float rssq[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) rssq[i] = 0.f;
-    if (p.row_ssq) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            int m = 16 * i + li;
-            m = m < p.M ? m : p.M - 1;
-            const float *src = p.row_ssq + m * p.row_nblk;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int j = 0;
-            for (; j + 4 <= p.row_nblk; j += 4) { s0 += src[j]; s1 += src[j + 1]; s2 += src[j + 2]; s3 += src[j + 3]; }
-            for (; j < p.row_nblk; ++j) s0 += src[j];
-            rssq[i] = (s0 + s1) + (s2 + s3);
-        }
-    }
     dma_stage(0, c0);
     // The weight ring is loaded with inline asm and waited for with hand-counted vmcnt: the compiler's waitcnt pass does not
     // count across a mix of LDS-DMA and register loads and would put vmcnt(0) - a full drain, DMA included - in front
@@ -1766,6 +1762,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
         const int cn = phys(c0 + u < c1 ? c0 + u : c1 - 1);
         ld_nt(wl[u], wh[u], wp + (int64_t)cn * 1024);
     }
+    // 1 / rms of the activation rows for the fused RMSNorm (GemmParams::row_ssq), used in the epilogue: the workgroup sums the
+    // producer's per-block sums of squares once, into LDS.  Requested BEHIND the first stage's DMA and weight loads (loads
+    // return in order: the wait the compiler puts in front of the sums also retires those, which the first MFMA needs anyway).
+    float *rstd_s = reinterpret_cast<float *>(smem + 2 * STAGE);
+    if (p.row_ssq) block_row_rstd<8, MP>(p.row_ssq, p.M, p.row_nblk, 1.0f / (float)p.K, p.norm_eps, rstd_s, wave, lane);
     int buf = 0, cs = c0;
     // Full stages run a branch-free body (DMA of the next stage when there is one, 8 x [MFMAs, clamped refill]).  With
     // conditional loads or a conditional DMA the compiler cannot count what is in flight and drains the whole queue - the
@@ -1860,7 +1861,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
     if (p.row_ssq) {   // RMSNorm of the activation rows, applied to the (linear) result: see GemmParams::row_ssq
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const float rs = rsqrtf(rssq[i] / (float)p.K + p.norm_eps);
+            const float rs = rstd_s[16 * i + li];           // (written before the main loop's barriers)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][r] *= rs;
         }
@@ -1909,7 +1910,7 @@ static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
         if (ks < 1) ks = 1;
     }
     if (p.ks_out) *p.ks_out = ks;
-    const int lds = 2 * (MT <= 4 ? 8 : 4) * 16 * MT * 128;
+    const int lds = 2 * (MT <= 4 ? 8 : 4) * 16 * MT * 128 + 16 * MT * (int)sizeof(float);   // two stages + the rows' 1 / rms
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_wide_kernel<MT, EPI>), lds);
     if (ea != hipSuccess) return ea;
     if (ks > 1 && p.row_ssq) {       // k-parts leave raw slabs: the row scale is applied by whoever combines them, not here
@@ -1943,6 +1944,7 @@ static hipError_t launch_mid_t(const GemmParams &p, hipStream_t s) {
         hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_mid_kernel<MT, EPI, NORM>), lds);
         if (ea != hipSuccess) return ea;
     }
+    if (p.row_ssq && ks == 1) return hipErrorInvalidValue;            // only the split-K reduce applies a row scale here
     OPUS_LAUNCH(KC_MID, (gemm_mid_kernel<MT, EPI, NORM>), dim3(blocks, ks), dim3(256), lds, s, p, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
@@ -1979,6 +1981,7 @@ static hipError_t launch_ring(const GemmParams &p, hipStream_t s, bool allow_spl
     }
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_ring_kernel<TM, TN, NS, EPI>), LDS);
     if (ea != hipSuccess) return ea;
+    if (p.row_ssq && ks == 1) return hipErrorInvalidValue;            // only the split-K reduce applies a row scale here
     OPUS_LAUNCH(KC_RING, (gemm_ring_kernel<TM, TN, NS, EPI>), dim3(bm * bn, ks), dim3(512), LDS, s, p, bm, bn, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
@@ -2015,6 +2018,7 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
         while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
         if (ks < 1) ks = 1;
     }
+    if (p.row_ssq && ks == 1) return hipErrorInvalidValue;            // only the split-K reduce applies a row scale here
     OPUS_LAUNCH(KC_TILE, (gemm_tile_kernel<EPI>), dim3(ntile * ks), dim3(256), 65536, s, p, tm, tn, ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ks == 1) return e;
@@ -2061,6 +2065,8 @@ static hipError_t launch_gemm_(const GemmParams &p, hipStream_t s, int *klass) {
     if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;   // (refined by the launch itself in timing mode: LaunchEvents::main_class)
     if (p.Af && !skinny && !mid) return hipErrorInvalidValue;   // fused norm: skinny and mid kernels only
     if (p.Af && p.epi == EPI_GELU) return hipErrorInvalidValue;
+    if ((p.a_tiled || p.c_tiled) && !(mid && p.N < 16384 && gemm_stream_ok(p))) return hipErrorInvalidValue;   // only gemm_stream_kernel reads / writes the fragment-ordered layout
+    if (p.row_ssq && skinny) return hipErrorInvalidValue;         // no row scale in the skinny kernel (fused norm instead)
     if (skinny) {
         if (p.Af) {
             switch (p.epi) {
@@ -2074,6 +2080,10 @@ static hipError_t launch_gemm_(const GemmParams &p, hipStream_t s, int *klass) {
             case EPI_GELU: return launch_skinny_e<EPI_GELU, false>(p, s);
             case EPI_SILU_GU16: return launch_skinny_e<EPI_SILU_GU16, false>(p, s);
         }
+    } else if (mid && !p.Af && !mid_v1 && p.N < 16384 && gemm_stream_ok(p)) {
+        // narrow outputs at 5..64 rows whose panels map onto the CUs (wo, down, QKV with two k-parts): one launch, K cut over
+        // the waves of a workgroup, no slabs / no reduce launch (gemm_stream.hip)
+        return launch_gemm_stream(p, s);
     } else if (mid && !p.Af && !mid_v1 && (p.N >= 16384 || p.force_wide || narrow_wide())) {
         // wide outputs (wgu, lm_head): one barrier per 512 k, weights through per-wave register rings
         const bool m2 = p.M <= 32;

@@ -1,0 +1,286 @@
+// gemm_stream: ONE-launch weight-streaming GEMM for the narrow projections of the batched decode step
+// (5 <= M <= 64 rows; QKV, wo, down of SURVEY 8a D3: N <= 6144 output columns, K = 4096 .. 14336).
+//
+// Why another kernel.  With 16 output columns per weight panel a 4096-column projection has 256 panels - one per CU - so
+// the kernels that share an activation slice between the panels of a workgroup through LDS (gemm_wide / gemm_ring) must
+// cut K over WORKGROUPS to fill the chip: fp32 slabs, a second launch to sum them, and 5-9 us of fixed cost around 5-13 us
+// of streaming (round 2: 2.6-2.9 TB/s on these shapes).  Here a workgroup owns P whole panels over the whole K (or over
+// one of `ksplit` k-parts) and cuts K over its WAVES instead:
+//   * wave w multiplies chunks w, w + NW, w + 2 NW, ... (64 k each) of the workgroup's panels: per chunk and panel one
+//     2-KB weight block straight from HBM to registers (non-temporal; the panel-tiled layout IS the MFMA A fragment) and,
+//     per 16-row tile, two 16-B-per-lane activation fragments straight from the L2-resident activation matrix into the
+//     MFMA B layout (buffer loads: rows >= M read as zeros) - no LDS staging, no barrier, no DMA in the main loop;
+//   * the NW partial tiles are combined through LDS in wave order (fixed order: bitwise reproducible, and a row's result
+//     does not depend on which rows share the launch), and the combining lanes own 4 consecutive columns of one row, so
+//     bias / residual / output / the fp16 copy move as 16-B / 8-B accesses;
+//   * with ksplit == 1 the epilogue is the whole GEMM epilogue, including the producer side of the row-scale RMSNorm
+//     fusion (GemmParams::xh_out / ssq_out: fp16(x) and the sum of squares of every 16-column block of the row);
+//     with ksplit > 1 (the QKV projection: 384 panels = 1.5 per CU, cut as 128 column groups x 2 k-parts) the k-parts
+//     leave raw fp32 slabs for the consumer (attn_decode_kernel sums them), as gemm_wide_kernel did with 5.
+// Cost model (measured, tools/bench_gemm.py narrow): a CU takes in at most ~67 GB/s through its L1 from L2, weights
+// included, and ~24 GB/s of that from HBM (1/256 of the chip's rate).  A workgroup moves 32 P bytes of weights per k and
+// 32 MT bytes of activations per k (MT = M / 16 row tiles): at 64 rows 160 K bytes per CU against 48 K for a k-split over 8
+// workgroups, so the kernel is activation-bound where M * K / ksplit is large (down at > 16 rows: the round-2 kernels keep
+// those) and HBM-bound + ~3.5 us of ramp elsewhere.
+// Activation layout.  A 16-row x 32-k MFMA B fragment read from a row-major matrix touches 16 lines with 64 bytes each
+// (42 GB/s per CU measured); read from a matrix stored in FRAGMENT order - the panel-tiled layout of the weights, with the
+// row in the place of the output column: block (row / 16, k / 64) = 2 KB, [k-step][lane = 16 (k % 32) / 8 + row % 16][8] -
+// it is one contiguous 1-KB wave access (66 GB/s).  GemmParams::a_tiled selects it; the producers of the decode step
+// (attn_decode_kernel, the embedding kernel, the epilogues that write fp16(x)) write that layout when asked to.
+#include "common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace opus {
+
+__device__ __forceinline__ float gelu_erf_s(float x) {   // same arithmetic as gemm.hip's gelu_erf
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// MT row tiles of 16, P panels per workgroup, NT threads, U chunk sets in flight per wave
+template <int MT, int P, int NT, int U, int EPI>
+__global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = NT / 64;
+    constexpr int TILES = P * MT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int chunks = p.K >> 6;
+    const int ky = blockIdx.y;
+    const int c0 = (int)((int64_t)chunks * ky / ksplit), c1 = (int)((int64_t)chunks * (ky + 1) / ksplit);
+    const int nck = c1 - c0;
+    const int nsteps = (nck + NW - 1) / NW;
+    const int panel0 = blockIdx.x * P;
+
+    const half_t *wp[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) wp[j] = p.W + ((int64_t)(panel0 + j) * chunks) * 1024 + lane * 8;
+    // activations through a buffer descriptor: lanes whose row does not exist get an out-of-range offset, for which the
+    // hardware returns zeros without touching memory and without a branch
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.A, 0, p.a_tiled ? MT * chunks * 2048 : (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    int aoff[MT];
+    const bool atiled = p.a_tiled != 0;
+    const int cstride = atiled ? 2048 : 128, sstride = atiled ? 1024 : 64;   // bytes between chunks / between the two k-steps
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = 16 * i + li;
+        if (atiled) aoff[i] = i * chunks * 2048 + lane * 16;
+        else aoff[i] = m < p.M ? (int)((m * p.lda + g * 8) * 2) : 0x40000000;
+    }
+    // rotated k-walk (memory-channel camping of the panel stride, see gemm_wide_kernel): a function of the column group and
+    // the k-part only
+    const int rot = (p.no_rot || nsteps < 2) ? 0 : (int)((blockIdx.x * 3u + (unsigned)ky) % (unsigned)nsteps);
+
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    h8 wr[U][P][2];
+    u4 ar[U][MT][2];
+    f4 acc[P][MT];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+
+    auto chunk_of = [&](int step) {          // chunk this wave multiplies in pipeline step `step` (may be >= c1: nothing)
+        int ph = step + rot;
+        ph = ph >= nsteps ? ph - nsteps : ph;
+        return c0 + ph * NW + wave;
+    };
+    auto load = [&](auto u_tag, int step) {
+        constexpr int u = decltype(u_tag)::value;
+        int c = chunk_of(step);
+        c = c < c1 ? c : c1 - 1;             // ragged last step: a harmless re-read, skipped by compute()
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const h8 *ptr = reinterpret_cast<const h8 *>(wp[j] + (int64_t)c * 1024);
+            wr[u][j][0] = __builtin_nontemporal_load(ptr);
+            wr[u][j][1] = __builtin_nontemporal_load(ptr + 64);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            ar[u][i][0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i] + c * cstride, 0, 0);
+            ar[u][i][1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i] + c * cstride + sstride, 0, 0);
+        }
+    };
+    auto compute = [&](auto u_tag, int step) {
+        constexpr int u = decltype(u_tag)::value;
+        if (chunk_of(step) >= c1) return;    // wave-uniform
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[u][j][0], __builtin_bit_cast(h8, ar[u][i][0]), acc[j][i], 0, 0, 0);   // C^T tile
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[u][j][1], __builtin_bit_cast(h8, ar[u][i][1]), acc[j][i], 0, 0, 0);
+            }
+    };
+    // U named sets: set u holds step s with s % U == u (static register indices)
+    auto for_sets = [&](auto &&f) {
+        f(std::integral_constant<int, 0>{});
+        if constexpr (U > 1) f(std::integral_constant<int, 1>{});
+        if constexpr (U > 2) f(std::integral_constant<int, 2>{});
+        if constexpr (U > 3) f(std::integral_constant<int, 3>{});
+    };
+    for_sets([&](auto u_tag) {
+        constexpr int u = decltype(u_tag)::value;
+        if (u < nsteps) load(u_tag, u);
+    });
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+        for_sets([&](auto u_tag) {
+            constexpr int u = decltype(u_tag)::value;
+            const int s = s0 + u;
+            if (s < nsteps) {
+                compute(u_tag, s);
+                if (s + U < nsteps) load(u_tag, s + U);
+            }
+        });
+    }
+
+    // ---- combine the NW partial tiles through LDS, in wave order ----
+    f4 *red = reinterpret_cast<f4 *>(smem);          // [NW][TILES][64] f4
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) red[(wave * TILES + j * MT + i) * 64 + lane] = acc[j][i];
+    __syncthreads();
+    const int npanels = p.N >> 4;
+    for (int tile = wave; tile < TILES; tile += NW) {    // wave-uniform
+        const int j = tile / MT, i = tile - j * MT;
+        f4 v = red[tile * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[(w * TILES + tile) * 64 + lane];
+        const int m = 16 * i + li;
+        const int panel = panel0 + j;
+        const int n = panel * 16 + 4 * g;                // this lane: columns n .. n + 3 of row m
+        const bool live = m < p.M;
+        if (ksplit > 1) {                                // raw k-part slab, no epilogue
+            if (live) *reinterpret_cast<float4 *>(p.ws + ((int64_t)ky * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            continue;
+        }
+        if (p.bias) {
+            const float4 bz = *reinterpret_cast<const float4 *>(p.bias + n);
+            v[0] += bz.x; v[1] += bz.y; v[2] += bz.z; v[3] += bz.w;
+        }
+        if (EPI == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf_s(v[r]);
+        }
+        if (p.residual && live) {
+            const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + n);
+            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+        if (live) {
+            if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (p.c_tiled ? tiled_off(m, n, p.N) : (int64_t)m * p.ldc + n)) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+        if (p.xh_out) {                                  // producer side of the row-scale RMSNorm fusion (wave-uniform)
+            if (live) *reinterpret_cast<h4 *>(p.xh_out + (p.xh_tiled ? tiled_off(m, n, p.N) : (int64_t)m * p.N + n)) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            q += __shfl_xor(q, 16, 64);                  // the four lanes (g = 0..3) of a row hold its 16 columns
+            q += __shfl_xor(q, 32, 64);
+            if (live && g == 0) p.ssq_out[(int64_t)m * npanels + panel] = q;
+        }
+    }
+}
+
+// ---- launcher ----
+struct StreamPlan { int P, ks, nt; };
+
+// P panels per workgroup x ks k-parts with (N / 16 / P) * ks workgroups on at most 256 CUs and at least 3/4 of them;
+// finished outputs need ks == 1 (no reduce launch: that is the point), slab consumers take ks <= 4.  The activation bytes a
+// CU re-reads from L2, 2 M K / ks, must stay within what its L1 takes in beside the weight stream (header): measured
+// break-even against the round-2 kernels at ~600 KB for fragment-ordered activations and ~280 KB for row-major ones.
+static bool stream_plan(int M, int N, int K, bool slab_only, bool a_tiled, int64_t ws_bytes, StreamPlan &pl) {
+    if ((N & 15) || (K & 63) || M < 1 || M > 64) return false;
+    const int npanels = N >> 4, chunks = K >> 6;
+    int best = 0;
+    const int cand[][2] = {{1, 1}, {3, 2}, {3, 4}};
+    for (auto &c : cand) {
+        const int P = c[0], ks = c[1];
+        if (npanels % P) continue;
+        if (ks > 1 && !slab_only) continue;
+        const int nt = P == 1 ? 1024 : 512;
+        if (chunks / ks < nt / 64) continue;              // at least one chunk per wave
+        const int wgs = npanels / P * ks;
+        if (wgs > 256 || wgs < 192) continue;
+        if (ks > 1 && (int64_t)ks * M * N * 4 > ws_bytes) continue;
+        if (2ll * M * K / ks > (a_tiled ? 600 : 280) * 1024) continue;
+        if (wgs > best) { best = wgs; pl = StreamPlan{P, ks, nt}; }
+    }
+    return best > 0;
+}
+
+static bool stream_off() {
+    static const bool off = getenv("OPUS_NO_STREAM") != nullptr;      // A/B aid
+    return off || g_knobs.no_stream;
+}
+
+// would launch_gemm route this fp16-A GEMM (EPI_NONE / GELU, 16-B aligned strides) to gemm_stream_kernel?
+bool gemm_stream_would(int M, int N, int K, int slab_only, int a_tiled, int row_scale, int64_t ws_bytes) {
+    StreamPlan pl;
+    if (stream_off() || !stream_plan(M, N, K, slab_only != 0, a_tiled != 0, ws_bytes, pl)) return false;
+    return !(row_scale && pl.ks == 1);
+}
+
+bool gemm_stream_ok(const GemmParams &p) {
+    if (p.Af || (p.epi != EPI_NONE && p.epi != EPI_GELU)) return false;
+    if ((p.ldc & 3) || (p.residual && (p.ldr & 3)) || (p.lda & 7)) return false;
+    if (!p.a_tiled && (int64_t)(p.M - 1) * p.lda + p.K >= (1ll << 29)) return false;   // 32-bit buffer offsets
+    if (p.a_tiled && p.lda != p.K) return false;
+    if ((p.c_tiled && (p.out_f32 || p.ldc != p.N))) return false;
+    // a row scale (GemmParams::row_ssq) is applied by whoever sums the slabs, never by this kernel's own epilogue
+    return gemm_stream_would(p.M, p.N, p.K, p.slab_only, p.a_tiled, p.row_ssq != nullptr, p.ws_bytes);
+}
+
+template <int MT, int P, int NT, int U, int EPI>
+static hipError_t launch_stream_t(const GemmParams &p_in, const StreamPlan &pl, hipStream_t s) {
+    GemmParams p = p_in;
+    constexpr int NW = NT / 64;
+    const size_t lds = (size_t)NW * P * MT * 1024;
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_stream_kernel<MT, P, NT, U, EPI>), lds);
+    if (ea != hipSuccess) return ea;
+    const int npanels = p.N >> 4;
+    // producer side of the row-scale fusion: fp32 output of the plain epilogue, room for M x N/16 partial sums
+    const bool fuse = pl.ks == 1 && EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 &&
+                      (int64_t)p.M * npanels <= p.ssq_cap;
+    if (fuse) { *p.fused_done = 1; if (p.nblk_out) *p.nblk_out = npanels; }
+    else p.xh_out = nullptr;
+    if (pl.ks > 1) p.row_ssq = nullptr;
+    if (p.ks_out) *p.ks_out = pl.ks;
+    OPUS_LAUNCH(KC_STREAM, (gemm_stream_kernel<MT, P, NT, U, EPI>), dim3(npanels / P, pl.ks), dim3(NT), lds, s, p, pl.ks);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_stream_e(const GemmParams &p, const StreamPlan &pl, hipStream_t s) {
+    const int mt = cdiv(p.M, 16);
+    if (pl.P == 1) {
+        switch (mt) {
+            case 1: return launch_stream_t<1, 1, 1024, 2, EPI>(p, pl, s);
+            case 2: return launch_stream_t<2, 1, 1024, 2, EPI>(p, pl, s);
+            case 3: return launch_stream_t<3, 1, 1024, 2, EPI>(p, pl, s);
+            case 4: return launch_stream_t<4, 1, 1024, 2, EPI>(p, pl, s);
+        }
+    } else {
+        switch (mt) {
+            case 1: return launch_stream_t<1, 3, 512, 2, EPI>(p, pl, s);
+            case 2: return launch_stream_t<2, 3, 512, 2, EPI>(p, pl, s);
+            case 3: return launch_stream_t<3, 3, 512, 2, EPI>(p, pl, s);
+            case 4: return launch_stream_t<4, 3, 512, 2, EPI>(p, pl, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_stream(const GemmParams &p, hipStream_t s) {
+    StreamPlan pl;
+    if (!gemm_stream_ok(p) || !stream_plan(p.M, p.N, p.K, p.slab_only != 0, p.a_tiled != 0, p.ws_bytes, pl)) return hipErrorInvalidValue;
+    if (p.epi == EPI_GELU) return launch_stream_e<EPI_GELU>(p, pl, s);
+    return launch_stream_e<EPI_NONE>(p, pl, s);
+}
+
+}  // namespace opus

@@ -370,3 +370,94 @@ def test_c5_shape_properties(dev):
     finally:
         del model
         torch.cuda.empty_cache()
+
+
+def _tile_rows(A16):
+    """[16 t, K] fp16 -> the fragment-ordered activation layout (== the panel-tiled weight layout, rows for output columns)"""
+    from opus_pllm_amd.weights import tile_weight
+    return tile_weight(A16.contiguous())
+
+
+# (M, N, K, tiled A): gemm_stream_kernel takes a narrow GEMM when the activation bytes a CU re-reads, 2 M K, stay below
+# 280 KB (row-major A) / 600 KB (fragment-ordered A) - gemm_stream.hip stream_plan
+@pytest.mark.parametrize("M,N,K,tiled", [(5, 4096, 4096, 0), (17, 4096, 4096, 0), (32, 4096, 4096, 0), (8, 4096, 14336, 0),
+                                         (5, 4096, 4096, 1), (32, 4096, 4096, 1), (40, 4096, 4096, 1), (64, 4096, 4096, 1),
+                                         (17, 4096, 14336, 1)])
+def test_stream_gemm_vs_fp64(big64, M, N, K, tiled):
+    """Row D3, kernel level: the one-launch narrow decode GEMM (gemm_stream_kernel: K cut over the waves of a workgroup,
+    partial tiles combined through LDS in wave order) as decode_step issues wo / down - X <- X + A W^T on the fp32 residual
+    stream - against fp64, bit-identical to itself when other rows share the launch (batch invariance) and whichever of the
+    two activation layouts it reads, and equal to the round-2 kernels (split-K + reduce) to fp32 rounding."""
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model = big64
+    dev = model.device
+    lib = _cabi.lib()
+    g = torch.Generator().manual_seed(M * 131 + K)
+    A = (torch.randn(64, K, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    X = torch.randn(64, N, generator=g) * 2.0
+    ref = X[:M].double() + A[:M].double() @ W.double().T
+    dA, dW = A.to(dev), tile_weight(W.to(dev))
+
+    def run(rows, stream_on, tiled_a):
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"no_stream", 0 if stream_on else 1))
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 1 if tiled_a else 0))
+        x = X[:rows].to(dev).contiguous()
+        if tiled_a:
+            pad = torch.zeros(-(-rows // 16) * 16, K, dtype=torch.float16, device=dev)
+            pad[:rows] = dA[:rows]
+            pad[rows:] = float("nan")                            # rows beyond M must not reach any stored output
+            a = _tile_rows(pad)
+        else:
+            a = dA[:rows].contiguous()
+        model.timing(True)
+        _cabi.check(lib.opus_debug_gemm(model._ctx, a.data_ptr(), dW.data_ptr(), None, x.data_ptr(), x.data_ptr(), rows, N, K, 0, 1, None))
+        torch.cuda.synchronize()
+        n_stream = model.timing_get("gemm_stream", "*")[1]
+        model.timing(False)
+        return x, n_stream
+
+    try:
+        out, n = run(M, True, tiled)
+        assert n == 1, "these shapes must take gemm_stream_kernel"
+        assert bool(torch.isfinite(out).all())
+        err = (out.double().cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item(), err
+        if 2 * 64 * K <= (600 if tiled else 280) * 1024:         # the same rows inside a 64-row launch: bit-identical
+            full, n64 = run(64, True, tiled)
+            assert n64 == 1 and torch.equal(full[:M], out)
+        if tiled and 2 * M * K <= 280 * 1024:                    # row-major A, same kernel: bit-identical
+            rm, nrm = run(M, True, 0)
+            assert nrm == 1 and torch.equal(rm, out)
+        old, n_old = run(M, False, 0)                            # the round-2 kernels (split-K + reduce)
+        assert n_old == 0
+        assert rel_l2(old, out) < 1e-5
+    finally:
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"no_stream", 0))
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 0))
+
+
+@pytest.mark.parametrize("M", [8, 32, 64])
+def test_stream_gemm_qkv_slabs_vs_fp64(big64, M):
+    """The QKV projection of the batched decode step (N = 6144: 384 panels = 128 column groups x 2 k-parts of
+    gemm_stream_kernel): the raw slabs summed in index order == A W^T in fp64."""
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model = big64
+    dev = model.device
+    lib = _cabi.lib()
+    N, K = 6144, 4096
+    g = torch.Generator().manual_seed(M * 17 + 3)
+    A = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    ref = A.double() @ W.double().T
+    dA, dW = A.to(dev), tile_weight(W.to(dev))
+    slabs = torch.zeros(8, M, N, dtype=torch.float32, device=dev)
+    ks = C.c_int32(-1)
+    _cabi.check(lib.opus_debug_gemm_slabs(model._ctx, dA.data_ptr(), dW.data_ptr(), slabs.data_ptr(), M, N, K, C.byref(ks), None))
+    torch.cuda.synchronize()
+    assert ks.value == 2, ks.value
+    got = slabs[0].double() + slabs[1].double()
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item(), err

@@ -13,7 +13,7 @@ from opus_pllm_amd.model import OpusLlamaForCausalLM
 from opus_pllm_amd.weights import DeviceWeights
 
 dev = torch.device("cuda:0")
-cfg = opa.micro()
+cfg = opa.micro(max_batch=64, max_prompt=104)
 model = OpusLlamaForCausalLM(cfg, DeviceWeights.synthetic(cfg, 0, dev), dev)
 lib = _cabi.lib()
 
@@ -77,7 +77,61 @@ def bench_tile(name, M, N, K, epi, f32out=False, resid=False, iters=20):
     print(f"{name:26s} M={M:6d} N={N:6d} K={K:6d} epi={epi} f32={int(f32out)} res={int(resid)}: {ms*1e3:9.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
 
 
+def bench_narrow(name, M, N, K, kind, iters=60):
+    """A/B of the narrow decode GEMMs in ONE process: gemm_stream_kernel (knob no_stream = 0) against the round-2 kernels
+    (no_stream = 1), alternating rounds, distinct weight buffers per launch (far beyond the Infinity Cache in total).
+    kind: "res" = X <- X + A W^T on the fp32 residual stream (wo / down); "slab" = the QKV projection leaving k-part slabs."""
+    import ctypes as C
+    bytes_ = 2 * N * K
+    nbuf = max(2, min(40, int(6e9 // bytes_)))
+    base = [(torch.randn(N * K // 2, device=dev) * 0.02).half().view(-1) for _ in range(2)]
+    bufs = [torch.cat([base[i % 2], base[(i + 1) % 2]]).clone() for i in range(nbuf)]
+    A = torch.randn(M, K, device=dev).half()
+    X = torch.randn(M, N, device=dev)
+    ks = C.c_int32(0)
+
+    def run(i):
+        w = bufs[i % nbuf]
+        if kind == "res":
+            _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), w.data_ptr(), None, X.data_ptr(), X.data_ptr(), M, N, K, 0, 1, None))
+        else:
+            _cabi.check(lib.opus_debug_gemm_slabs(model._ctx, A.data_ptr(), w.data_ptr(), None, M, N, K, C.byref(ks), None))
+    res = {0: [], 1: []}
+    for rnd in range(4):
+        for off in (0, 1):
+            _cabi.check(lib.opus_debug_knob(model._ctx, b"no_stream", off))
+            _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 0 if off else TILED))   # (timing only: A is not re-tiled)
+            for i in range(3):
+                run(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(iters):
+                run(i + 3)
+            e1.record()
+            torch.cuda.synchronize()
+            res[off].append(e0.elapsed_time(e1) / iters * 1e3)
+    _cabi.check(lib.opus_debug_knob(model._ctx, b"no_stream", 0))
+    _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 0))
+    new, old = min(res[0]), min(res[1])
+    print(f"{name:10s} M={M:3d} N={N:6d} K={K:6d}: stream {new:7.2f} us ({bytes_/new/1e6:5.2f} TB/s)   round-2 kernels {old:7.2f} us "
+          f"({bytes_/old/1e6:5.2f} TB/s)   [rounds: {' '.join(f'{x:.1f}' for x in res[0])} | {' '.join(f'{x:.1f}' for x in res[1])}]", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "narrow":
+        TILED = 0
+        for k in sys.argv[2:]:                      # knob=value ...
+            name, v = k.split("=")
+            if name == "debug_a_tiled":
+                TILED = int(v)
+            else:
+                _cabi.check(lib.opus_debug_knob(model._ctx, name.encode(), int(v)))
+        for M in ((64,) if os.environ.get("M64") else (8, 16, 32, 48, 64)):
+            bench_narrow("wo", M, 4096, 4096, "res")
+            bench_narrow("down", M, 4096, 14336, "res")
+            bench_narrow("qkv", M, 6144, 4096, "slab")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tile":
         for M in (32896, 514):
             bench_tile("esm qkv", M, 3840, 1280, 0)
