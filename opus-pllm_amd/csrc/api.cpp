@@ -112,7 +112,7 @@ struct opus_ctx {
     // one-shot requests for the next gemm(): route a narrow output through the wide kernel / leave raw k-part slabs
     int rq_force_wide = 0, rq_slab_only = 0, rq_ks = 1;
     // one-shot: the next gemm() reads A / writes the fp16 copy of its output in fragment order (GemmParams::a_tiled / xh_tiled)
-    int rq_a_tiled = 0, rq_xh_tiled = 0;
+    int rq_a_tiled = 0, rq_xh_tiled = 0, rq_c_tiled = 0;
     bool xln_tiled = false;              // d_xln currently holds fp16(x) in fragment order
     const float *xh_src = nullptr;       // fp32 buffer whose fp16 copy + sum-of-squares partials are valid
     bool use_row_scale = false;          // one-shot: the next gemm() multiplies its rows by the rstd from d_ssq
@@ -485,8 +485,8 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     c->rq_ks = 1;
     p.force_wide = c->rq_force_wide; p.slab_only = c->rq_slab_only; p.ks_out = &c->rq_ks;
     c->rq_force_wide = c->rq_slab_only = 0;
-    p.a_tiled = c->rq_a_tiled; p.xh_tiled = c->rq_xh_tiled;
-    c->rq_a_tiled = c->rq_xh_tiled = 0;
+    p.a_tiled = c->rq_a_tiled; p.xh_tiled = c->rq_xh_tiled; p.c_tiled = c->rq_c_tiled;
+    c->rq_a_tiled = c->rq_xh_tiled = c->rq_c_tiled = 0;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
     // algorithmic bytes: the weights once + activations in + result out (+ the residual read)
     const double bytes = 2.0 * N * K + (Af ? 4.0 : 2.0) * M * K + (double)M * nout * (out_f32 ? 4 : 2) +
@@ -905,6 +905,7 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     // layer 0, the down projection's epilogue / reduce afterwards) and the attention output for the wo projection.
     const bool qkv_tiled = rowscale && gemm_stream_would(B, QKV, H, 1, 1, 1, c->gemm_ws_bytes);
     const bool wo_tiled = rowscale && gemm_stream_would(B, H, QD, 0, 1, 0, c->gemm_ws_bytes);
+    const bool down_tiled = rowscale && (F & 63) == 0 && gemm_stream_would(B, H, F, 0, 1, 0, c->gemm_ws_bytes);
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, rowscale ? c->d_xln : nullptr,
                                                   rowscale ? c->d_ssq : nullptr, qkv_tiled ? 1 : 0, s));
     c->xln_tiled = qkv_tiled;
@@ -958,9 +959,14 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
         c->rq_a_tiled = wo_tiled ? 1 : 0;
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, B, H, QD, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
         c->xh_src = c->rq_done ? c->d_xl : nullptr;
+        // the gate / up kernel writes silu(g) u in fragment order when the down projection will read it that way (only the wide
+        // kernel - the row-scale form of gemm_norm - writes that layout)
+        const bool act_tiled = down_tiled && c->xh_src == c->d_xl && gemm_goes_wide(B, 2 * F);
+        c->rq_c_tiled = act_tiled ? 1 : 0;
         OPC(gemm_norm(c, s, c->d_xl, g.dec_rms_eps, c->d_xln, L.wgu, B, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
         const bool next_tiled = qkv_tiled && l + 1 < g.dec_layers;      // (the last layer's fp16(x) feeds lm_head: row-major)
         if (fuse_rows() && B <= 96) { c->rq_xh = c->d_xln; c->rq_xh_tiled = next_tiled ? 1 : 0; }
+        c->rq_a_tiled = act_tiled ? 1 : 0;
         OPC(gemm(c, s, c->d_act, F, L.wd, B, H, F, nullptr, EPI_NONE, c->d_xl, c->d_xl, H, 1));
         c->xh_src = c->rq_done ? c->d_xl : nullptr;
         c->xln_tiled = c->rq_done && next_tiled;

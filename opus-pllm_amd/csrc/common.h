@@ -140,6 +140,7 @@ struct AttnParams {
 
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass);
 // gemm_stream.hip: one-launch weight streaming for narrow outputs at 5..64 rows (K cut over the waves of a workgroup)
+hipError_t launch_splitk_reduce(const GemmParams &p, int ks, hipStream_t s);   // gemm.hip: sums the k-part slabs in p.ws, applies the epilogue
 bool gemm_stream_ok(const GemmParams &p);
 bool gemm_stream_would(int M, int N, int K, int slab_only, int a_tiled, int row_scale, int64_t ws_bytes);
 hipError_t launch_gemm_stream(const GemmParams &p, hipStream_t s);

@@ -346,7 +346,7 @@ __device__ __forceinline__ void store4(const GemmParams &p, int m, int nb, f4 v,
             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
         }
         if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nb) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (p.c_tiled ? tiled_off(m, nb, nlim) : (int64_t)m * p.ldc + nb)) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -354,7 +354,7 @@ __device__ __forceinline__ void store4(const GemmParams &p, int m, int nb, f4 v,
             float x = v[r];
             if (p.residual) x += p.residual[(int64_t)m * p.ldr + nb + r];
             if (p.out_f32) reinterpret_cast<float *>(p.C)[(int64_t)m * p.ldc + nb + r] = x;
-            else reinterpret_cast<half_t *>(p.C)[(int64_t)m * p.ldc + nb + r] = (half_t)x;
+            else reinterpret_cast<half_t *>(p.C)[p.c_tiled ? tiled_off(m, nb + r, nlim) : (int64_t)m * p.ldc + nb + r] = (half_t)x;
         }
     }
 }
@@ -1668,6 +1668,15 @@ static hipError_t launch_reduce(const GemmParams &p, int ks, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_splitk_reduce(const GemmParams &p, int ks, hipStream_t s) {
+    switch (p.epi) {
+        case EPI_NONE: return launch_reduce<EPI_NONE>(p, ks, s);
+        case EPI_GELU: return launch_reduce<EPI_GELU>(p, ks, s);
+        case EPI_SILU_GU16: return launch_reduce<EPI_SILU_GU16>(p, ks, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 // ------------------------------------------------------------------------------------------------
 // wide (16 < M <= 64, fp16 activations): batched-decode weight streaming with ONE barrier per 512 k.
 // Workgroup = 8 waves = 8 weight panels (128 output columns) x all M rows x one k-part.  The [M x 512]
@@ -2065,7 +2074,11 @@ static hipError_t launch_gemm_(const GemmParams &p, hipStream_t s, int *klass) {
     if (klass) *klass = skinny ? KC_SKINNY : KC_TILE;   // (refined by the launch itself in timing mode: LaunchEvents::main_class)
     if (p.Af && !skinny && !mid) return hipErrorInvalidValue;   // fused norm: skinny and mid kernels only
     if (p.Af && p.epi == EPI_GELU) return hipErrorInvalidValue;
-    if ((p.a_tiled || p.c_tiled) && !(mid && p.N < 16384 && gemm_stream_ok(p))) return hipErrorInvalidValue;   // only gemm_stream_kernel reads / writes the fragment-ordered layout
+    // the fragment-ordered activation layout: read by gemm_stream_kernel only; written (fp16 C) by it and by gemm_wide_kernel
+    const bool to_stream = mid && !p.Af && p.N < 16384 && gemm_stream_ok(p);
+    const bool to_wide = !to_stream && mid && !p.Af && !mid_v1 && (p.N >= 16384 || p.force_wide || narrow_wide());
+    if (p.a_tiled && !to_stream) return hipErrorInvalidValue;
+    if (p.c_tiled && (p.out_f32 || !(to_stream || to_wide) || ((p.epi == EPI_SILU_GU16 ? p.N / 2 : p.N) & 63))) return hipErrorInvalidValue;
     if (p.row_ssq && skinny) return hipErrorInvalidValue;         // no row scale in the skinny kernel (fused norm instead)
     if (skinny) {
         if (p.Af) {

@@ -190,19 +190,22 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
 // ---- launcher ----
 struct StreamPlan { int P, ks, nt; };
 
-// P panels per workgroup x ks k-parts with (N / 16 / P) * ks workgroups on at most 256 CUs and at least 3/4 of them;
-// finished outputs need ks == 1 (no reduce launch: that is the point), slab consumers take ks <= 4.  The activation bytes a
+// P panels per workgroup x ks k-parts with (N / 16 / P) * ks workgroups on at most 256 CUs and at least 3/4 of them.
+// ks == 1 writes the finished output (no slabs, no reduce launch); ks > 1 leaves slabs - for a consumer that sums them
+// (slab_only: the QKV projection, 3 panels x 2 k-parts) or for splitk_reduce behind the launch (the down projection at
+// > 16 rows: 4 panels x 4 k-parts cut the activation bytes per CU by 4, which an in-workgroup k-split cannot).  The activation bytes a
 // CU re-reads from L2, 2 M K / ks, must stay within what its L1 takes in beside the weight stream (header): measured
 // break-even against the round-2 kernels at ~600 KB for fragment-ordered activations and ~280 KB for row-major ones.
 static bool stream_plan(int M, int N, int K, bool slab_only, bool a_tiled, int64_t ws_bytes, StreamPlan &pl) {
     if ((N & 15) || (K & 63) || M < 1 || M > 64) return false;
     const int npanels = N >> 4, chunks = K >> 6;
     int best = 0;
-    const int cand[][2] = {{1, 1}, {3, 2}, {3, 4}};
+    const int cand[][2] = {{1, 1}, {3, 2}, {3, 4}, {4, 4}};            // (ties: the earlier candidate, i.e. the smaller ks)
     for (auto &c : cand) {
         const int P = c[0], ks = c[1];
         if (npanels % P) continue;
-        if (ks > 1 && !slab_only) continue;
+        if (P == 3 && !slab_only) continue;
+        if (P == 4 && (slab_only || !a_tiled)) continue;
         const int nt = P == 1 ? 1024 : 512;
         if (chunks / ks < nt / 64) continue;              // at least one chunk per wave
         const int wgs = npanels / P * ks;
@@ -223,7 +226,7 @@ static bool stream_off() {
 bool gemm_stream_would(int M, int N, int K, int slab_only, int a_tiled, int row_scale, int64_t ws_bytes) {
     StreamPlan pl;
     if (stream_off() || !stream_plan(M, N, K, slab_only != 0, a_tiled != 0, ws_bytes, pl)) return false;
-    return !(row_scale && pl.ks == 1);
+    return !(row_scale && pl.ks == 1);                                // (no row scale in this kernel's own epilogue)
 }
 
 bool gemm_stream_ok(const GemmParams &p) {
@@ -252,12 +255,22 @@ static hipError_t launch_stream_t(const GemmParams &p_in, const StreamPlan &pl, 
     if (pl.ks > 1) p.row_ssq = nullptr;
     if (p.ks_out) *p.ks_out = pl.ks;
     OPUS_LAUNCH(KC_STREAM, (gemm_stream_kernel<MT, P, NT, U, EPI>), dim3(npanels / P, pl.ks), dim3(NT), lds, s, p, pl.ks);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || pl.ks == 1 || p_in.slab_only) return e;
+    return launch_splitk_reduce(p_in, pl.ks, s);                      // (applies bias / residual / row scale, writes xh_out + sums of squares)
 }
 
 template <int EPI>
 static hipError_t launch_stream_e(const GemmParams &p, const StreamPlan &pl, hipStream_t s) {
     const int mt = cdiv(p.M, 16);
+    if (pl.P == 4) {
+        switch (mt) {
+            case 1: return launch_stream_t<1, 4, 512, 2, EPI>(p, pl, s);
+            case 2: return launch_stream_t<2, 4, 512, 2, EPI>(p, pl, s);
+            case 3: return launch_stream_t<3, 4, 512, 2, EPI>(p, pl, s);
+            case 4: return launch_stream_t<4, 4, 512, 2, EPI>(p, pl, s);
+        }
+    }
     if (pl.P == 1) {
         switch (mt) {
             case 1: return launch_stream_t<1, 1, 1024, 2, EPI>(p, pl, s);

@@ -378,11 +378,12 @@ def _tile_rows(A16):
     return tile_weight(A16.contiguous())
 
 
-# (M, N, K, tiled A): gemm_stream_kernel takes a narrow GEMM when the activation bytes a CU re-reads, 2 M K, stay below
-# 280 KB (row-major A) / 600 KB (fragment-ordered A) - gemm_stream.hip stream_plan
+# (M, N, K, tiled A): gemm_stream_kernel takes a narrow GEMM when the activation bytes a CU re-reads, 2 M K / ksplit, stay
+# below 280 KB (row-major A) / 600 KB (fragment-ordered A) - gemm_stream.hip stream_plan; the last two cases are the down
+# projection at > 16 rows: 4 panels x 4 k-parts per workgroup, slabs summed by splitk_reduce4 behind the launch
 @pytest.mark.parametrize("M,N,K,tiled", [(5, 4096, 4096, 0), (17, 4096, 4096, 0), (32, 4096, 4096, 0), (8, 4096, 14336, 0),
                                          (5, 4096, 4096, 1), (32, 4096, 4096, 1), (40, 4096, 4096, 1), (64, 4096, 4096, 1),
-                                         (17, 4096, 14336, 1)])
+                                         (17, 4096, 14336, 1), (40, 4096, 14336, 1), (64, 4096, 14336, 1)])
 def test_stream_gemm_vs_fp64(big64, M, N, K, tiled):
     """Row D3, kernel level: the one-launch narrow decode GEMM (gemm_stream_kernel: K cut over the waves of a workgroup,
     partial tiles combined through LDS in wave order) as decode_step issues wo / down - X <- X + A W^T on the fp32 residual

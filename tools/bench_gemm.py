@@ -100,7 +100,8 @@ def bench_narrow(name, M, N, K, kind, iters=60):
     for rnd in range(4):
         for off in (0, 1):
             _cabi.check(lib.opus_debug_knob(model._ctx, b"no_stream", off))
-            _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 0 if off else TILED))   # (timing only: A is not re-tiled)
+            # (timing only: A is not re-tiled; row-major where the planner would not take the tiled form)
+            _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 0 if off or (kind == "res" and 2 * M * K > 600 * 1024 * (4 if N == 4096 else 1)) else TILED))
             for i in range(3):
                 run(i)
             torch.cuda.synchronize()
