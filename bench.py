@@ -181,7 +181,7 @@ def timed(work, a, world, rank, dev, dist, cdev, steps, warmup):
 
 
 # ------------------------------------------------------------------------------------------------ roofline
-HBM_CLASSES = ("gemm_skinny", "gemm_mid", "gemm_wide", "gemm_stream", "attn_decode", "splitk_reduce", "norm", "other", "decode_stack")
+HBM_CLASSES = ("gemm_skinny", "gemm_mid", "gemm_wide", "gemm_stream", "attn_decode", "splitk_reduce", "norm", "other")
 
 
 def roofline(model, work, dev):

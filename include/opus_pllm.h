@@ -149,6 +149,12 @@ int opus_generate_greedy(opus_ctx *ctx, const void *d_embeds, const uint8_t *d_m
                          int32_t max_new, const int32_t *eos_ids, int32_t n_eos, int32_t pad_id,
                          int32_t *d_out_ids, int32_t *n_out, void *stream);
 
+/* Row N2, "### early-stop as an opt-in" (the reference decodes to max_new_tokens and cuts the text at the first "###"
+ * afterwards, eval/run_opus_ddp.py:19-27): with the token ids of "###" set here (HOST array, at most 8; n = 0 clears), a row
+ * is finished once its new ids end with that sequence - later positions hold pad_id, as after an EOS - so the text after the
+ * cut is unchanged and a batch can stop early.  Applies to opus_generate_greedy / opus_generate_sample of this context. */
+int opus_set_stop_sequence(opus_ctx *ctx, const int32_t *ids, int32_t n);
+
 /* Row N1 (sampling head, the reference's default decode mode: run_opus_ddp.py:126-128,156-157 temperature 0.1,
  * top_p 0.7): same loop with next = multinomial(softmax(top_p_filter(logits / temperature))) per transformers'
  * TemperatureLogitsWarper + TopPLogitsWarper; draws come from a counter-based generator keyed by

@@ -83,6 +83,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "opus_timing_names": (C.c_int, [C.c_char_p, C.c_int32]),
     "opus_last_logits": (C.c_int, [_P, _P, C.c_int32, _P]),
+    "opus_set_stop_sequence": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
     "opus_debug_gemm_slabs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P]),
     "opus_debug_knob": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "opus_debug_gemm_rowscale": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

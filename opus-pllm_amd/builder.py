@@ -249,6 +249,20 @@ def _esm2_ckpt_path() -> str:
 
 
 # ------------------------------------------------------------------------------------------------ entry point
+def resolve_eos_token_id(hf_cfg: dict, tokenizer_eos, model_base_path: str):
+    """The ids HF generate() stops on: model.generation_config.eos_token_id, which from_pretrained (model/builder.py:61-65)
+    takes from generation_config.json when that file exists (Llama-3-Instruct lists [128001, 128009] there and a single id
+    in config.json), else from config.json, else from the tokenizer.  An explicit `"eos_token_id": null` in
+    generation_config.json means what it means to HF: no stop id (generation runs to max_new_tokens).  Returns an int, a list
+    of ints or None - OpusLlamaForCausalLM normalises it to a list."""
+    eos = hf_cfg.get("eos_token_id", tokenizer_eos)
+    gc_path = os.path.join(model_base_path, "generation_config.json")
+    if os.path.exists(gc_path):
+        with open(gc_path) as f:
+            eos = json.load(f).get("eos_token_id", eos)
+    return eos
+
+
 def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=False, load_4bit=False, accelerator=None,
                           switch_projector_type="mlp2x_gelu", cstp_path=True, **kwargs):
     """-> (tokenizer, model, context_len), as model/builder.py:29-131.
@@ -327,13 +341,7 @@ def load_pretrained_model(model_base_path, adapter_path, model_name, load_8bit=F
     esm = torch.load(_esm2_ckpt_path(), map_location="cpu", weights_only=False)
     canon.update(canonical_from_esm2(esm.get("model", esm), cfg))
     weights = DeviceWeights.from_canonical(cfg, canon, device, lora=lora)
-    # HF generate() stops on model.generation_config, which from_pretrained reads from generation_config.json when the
-    # file exists (Llama-3-Instruct lists [128001, 128009] there and a single id in config.json)
-    eos = hf_cfg.get("eos_token_id", tokenizer.eos_token_id)
-    gc_path = os.path.join(model_base_path, "generation_config.json")
-    if os.path.exists(gc_path):
-        with open(gc_path) as f:
-            eos = json.load(f).get("eos_token_id", eos)
+    eos = resolve_eos_token_id(hf_cfg, tokenizer.eos_token_id, model_base_path)
     model = OpusLlamaForCausalLM(cfg, weights, device, eos_token_id=eos, pad_token_id=tokenizer.pad_token_id)
     context_len = hf_cfg.get("max_sequence_length", 512)     # builder.py:126-129
     return tokenizer, model, context_len

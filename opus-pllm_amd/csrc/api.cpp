@@ -86,8 +86,9 @@ struct opus_ctx {
     float samp_temp = 0.f, samp_top_p = 1.f;
     int64_t gemm_ws_bytes = 0;
     half_t *d_xn, *d_qkv, *d_ctx, *d_act, *d_xln, *kc, *vc;
-    float *cs_enc, *cs_dec;
-    int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan, *d_pidx;
+    float *cs_enc, *cs_dec, *cs_row;
+    int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan, *d_pidx, *d_stop;
+    int n_stop = 0;                      // opt-in stop sequence (opus_set_stop_sequence)
     int64_t cache_sl, cache_sb, cache_sh;   // strides (halfs): layer, batch row, kv head
     // decode state
     int cur_B = 0, cur_T = 0;
@@ -97,11 +98,6 @@ struct opus_ctx {
     int g_B = -1, g_T = -1, g_maxnew = -1, g_pad = 0, g_neos = -1;
     const int32_t *g_out = nullptr;
     float g_temp = 0.f, g_top_p = 1.f;
-    // persistent decode-step kernel: per-layer weight table and grid-barrier words (device)
-    StackLayer *d_stack_layers = nullptr;
-    unsigned *d_bar = nullptr;
-    unsigned long long *d_trace = nullptr;
-    bool stack_used = false, g_stack = false;
     // row-scale fusion (GemmParams::xh_out / row_ssq): one-shot request for the next gemm() and its outcome
     half_t *rq_xh = nullptr;
     int rq_done = 0;
@@ -124,8 +120,11 @@ struct opus_ctx {
     bool timing = false;
     int phase = PH_OTHER;
     std::vector<TimeRec> recs;
-    // rows the projector workspace (p_xn, p_y, p_z) holds: larger batches are projected in chunks of this many rows
+    // rows the projector workspace (p_xn, p_y, p_z) holds: larger batches are projected in chunks of this many rows.  The
+    // context's own workspace holds max_batch rows; the first call with more rows (the batched stage of the two-stage
+    // pipeline) allocates a separate BIG_PROJ_ROWS-row workspace (proj_big) and switches to it.
     int proj_rows = 0;
+    char *proj_big = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -154,8 +153,7 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->e_ctx = k.take<half_t>(Me * De);
     c->e_h1 = k.take<half_t>(Me * Fe);
     const size_t B = g.max_batch, H = g.dec_dim, SW = (size_t)g.dec_dim * g.n_prot_tokens;
-    // the projectors also serve the batched stage of the two-stage pipeline (whole shards at M >= 512)
-    const size_t PR = B > 4096 ? B : 4096;      // (the 8H x 8H GEMM runs 1.18 / 1.30 / 1.34 PFLOP/s at 512 / 1024 / 4096 rows)
+    const size_t PR = B;                         // (the two-stage pipeline's big workspace is allocated on first use: ensure_proj_rows)
     c->proj_rows = (int)PR;
     c->p_xn = k.take<half_t>(PR * De);
     c->p_y = k.take<half_t>(PR * (size_t)(g.has_protein_projector ? g.proj_dim : g.enc_dim));
@@ -184,12 +182,14 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     const size_t maxpos_e = g.max_enc_tokens, maxpos_d = ctx;
     c->cs_enc = k.take<float>(maxpos_e * (g.enc_dim / g.enc_heads));
     c->cs_dec = k.take<float>(maxpos_d * g.dec_head_dim);
+    c->cs_row = k.take<float>(B * (size_t)g.dec_head_dim);          // (cos, sin) rows of the current decode step, one per batch row
     c->d_kstart = k.take<int32_t>(B + 4);
     c->d_step = k.take<int32_t>(4);
     c->d_next = k.take<int32_t>(B);
     c->d_fin = k.take<int32_t>(B);
     c->d_nunf = k.take<int32_t>((size_t)g.max_new_tokens + 4);
     c->d_eos = k.take<int32_t>(64);
+    c->d_stop = k.take<int32_t>(16);
     c->d_plan = k.take<int32_t>(4 * B + 8);
     c->d_pval = k.take<float>(64 * B);
     c->d_probs = k.take<float>(B * ((size_t)g.dec_vocab + 64 * 4));     // candidate probabilities (per-part slots)
@@ -287,6 +287,9 @@ extern "C" int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **ou
         for (size_t i = 0; i < t.size(); i += 2) { t[i] = 1.0f; t[i + 1] = 0.0f; }
     HIPC(hipMemcpy(c->cs_dec, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPC(hipMemset(c->d_step, 0, 16));
+    // the decode attention reads whole 32-slot tiles and masks afterwards: every cache slot must hold finite values
+    HIPC(hipMemset(c->kc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
+    HIPC(hipMemset(c->vc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
     *out = c;
     return OPUS_OK;
 }
@@ -305,8 +308,7 @@ extern "C" int opus_ctx_destroy(opus_ctx *c) {
     timing_clear(c);
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->ws) (void)hipFree(c->ws);
-    if (c->d_stack_layers) (void)hipFree(c->d_stack_layers);
-    if (c->d_bar) (void)hipFree(c->d_bar);
+    if (c->proj_big) (void)hipFree(c->proj_big);
     delete c;
     return OPUS_OK;
 }
@@ -417,15 +419,6 @@ extern "C" int opus_weights_ready(opus_ctx *c) {
         GW("dec.lnf.b", OPUS_F32, (std::vector<int64_t>{H}), c->dec_lnfb);
     }
     GW("dec.lm_head", OPUS_F16, (std::vector<int64_t>{V, H}), c->lm_head);
-    {
-        std::vector<StackLayer> tab(g.dec_layers);
-        for (int l = 0; l < g.dec_layers; ++l) tab[l] = StackLayer{c->dec[l].wqkv, c->dec[l].wo, c->dec[l].wgu, c->dec[l].wd};   // (arch 0)
-        if (!c->d_stack_layers) HIPC(hipMalloc(&c->d_stack_layers, tab.size() * sizeof(StackLayer)));
-        HIPC(hipMemcpy(c->d_stack_layers, tab.data(), tab.size() * sizeof(StackLayer), hipMemcpyHostToDevice));
-        const size_t bar_words = 1024 + 16 * 1024;                 // counters + 16 "go" words 4 KB apart
-        if (!c->d_bar) HIPC(hipMalloc(&c->d_bar, bar_words * sizeof(unsigned)));
-        HIPC(hipMemset(c->d_bar, 0, bar_words * sizeof(unsigned)));
-    }
     c->resolved = true;
     return OPUS_OK;
 }
@@ -629,6 +622,26 @@ extern "C" int opus_esm2_last_hidden(opus_ctx *c, float *d_out, int32_t B, int32
 }
 
 // ------------------------------------------------------------------------------------------------ projectors
+// The projectors also serve the batched stage of the two-stage pipeline (whole shards at M >= 512; the 8H x 8H
+// GEMM runs 1.18 / 1.30 / 1.34 PFLOP/s at 512 / 1024 / 4096 rows).  Its workspace (0.55 GB at the Llama-3-8B shape) is not
+// part of every context: the first call that brings more rows than max_batch allocates it.
+constexpr int BIG_PROJ_ROWS = 4096;
+static int ensure_proj_rows(opus_ctx *c, int B) {
+    if (B <= c->proj_rows || c->proj_big) return OPUS_OK;
+    const opus_config &g = c->cfg;
+    const size_t PR = BIG_PROJ_ROWS > g.max_batch ? BIG_PROJ_ROWS : g.max_batch;
+    const size_t De = g.enc_dim, Dm = g.has_protein_projector ? g.proj_dim : g.enc_dim, SW = (size_t)g.dec_dim * g.n_prot_tokens;
+    const size_t bytes = (align_up(PR * De * 2) + align_up(PR * Dm * 2) + 2 * align_up(PR * SW * 2));
+    HIPC(hipMalloc((void **)&c->proj_big, bytes));
+    Carver k{c->proj_big};
+    c->p_xn = k.take<half_t>(PR * De);
+    c->p_y = k.take<half_t>(PR * Dm);
+    c->p_z[0] = k.take<half_t>(PR * SW);
+    c->p_z[1] = k.take<half_t>(PR * SW);
+    c->proj_rows = (int)PR;
+    return OPUS_OK;
+}
+
 // The projector workspace holds c->proj_rows rows; larger inputs (the batched stage of the two-stage pipeline, SURVEY 8f N3:
 // whole dataset shards at M >= 512, where the switch-projector GEMMs are MFMA-bound) are processed in chunks of that size.
 static int protein_projector_rows(opus_ctx *c, hipStream_t s, const float *d_pooled, int B, half_t *d_out) {
@@ -666,6 +679,7 @@ extern "C" int opus_protein_projector(opus_ctx *c, const float *d_pooled, int32_
     const opus_config &g = c->cfg;
     const int64_t din = g.enc_dim, dout = g.has_protein_projector ? g.proj_dim : g.enc_dim;
     c->phase = PH_PROJECT;
+    OPC(ensure_proj_rows(c, B));
     for (int r0 = 0; r0 < B; r0 += c->proj_rows) {
         const int n = B - r0 < c->proj_rows ? B - r0 : c->proj_rows;
         OPC(protein_projector_rows(c, (hipStream_t)stream, d_pooled + r0 * din, n, (half_t *)d_out + r0 * dout));
@@ -680,6 +694,7 @@ extern "C" int opus_switch_projector(opus_ctx *c, const void *d_in, int32_t B, v
     const opus_config &g = c->cfg;
     const int64_t din = g.has_protein_projector ? g.proj_dim : g.enc_dim, SW = (int64_t)g.dec_dim * g.n_prot_tokens;
     c->phase = PH_PROJECT;
+    OPC(ensure_proj_rows(c, B));
     for (int r0 = 0; r0 < B; r0 += c->proj_rows) {
         const int n = B - r0 < c->proj_rows ? B - r0 : c->proj_rows;
         OPC(switch_projector_rows(c, (hipStream_t)stream, (const half_t *)d_in + r0 * din, n, (half_t *)d_out + r0 * SW));
@@ -696,6 +711,7 @@ extern "C" int opus_projector_forward(opus_ctx *c, const float *d_pooled, int32_
     hipStream_t s = (hipStream_t)stream;
     const int64_t din = g.enc_dim, dmid = g.has_protein_projector ? g.proj_dim : g.enc_dim, SW = (int64_t)g.dec_dim * g.n_prot_tokens;
     c->phase = PH_PROJECT;
+    OPC(ensure_proj_rows(c, B));
     for (int r0 = 0; r0 < B; r0 += c->proj_rows) {
         const int n = B - r0 < c->proj_rows ? B - r0 : c->proj_rows;
         OPC(protein_projector_rows(c, s, d_pooled + r0 * din, n, c->p_y));
@@ -752,7 +768,7 @@ static int attn_decode(opus_ctx *c, hipStream_t s, int l, int B, int T, int slab
         a.qkv = nullptr; a.slabs = c->gemm_ws; a.ks = slab_ks; a.slab_stride = (int64_t)B * QKVd;
         a.row_ssq = c->d_ssq; a.row_nblk = c->ssq_nblk; a.eps = g.dec_rms_eps; a.K = g.dec_dim; a.bias = bias;
     }
-    a.cs = c->cs_dec; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = T; a.nh = g.dec_heads; a.nkv = g.dec_kv_heads;
+    a.cs_row = c->cs_row; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = T; a.nh = g.dec_heads; a.nkv = g.dec_kv_heads;
     a.kc = c->kc + l * c->cache_sl; a.vc = c->vc + l * c->cache_sl; a.cache_sb = c->cache_sb; a.cache_sh = c->cache_sh;
     a.ctx_cap = g.max_prompt + g.max_new_tokens; a.scale = 1.0f / sqrtf((float)g.dec_head_dim); a.out = c->d_ctx;
     a.out_tiled = out_tiled;
@@ -869,24 +885,6 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
     return OPUS_OK;
 }
 
-// OPUS_STACK=1 routes decode steps at batch <= 4 through the single-launch persistent kernel (decode_stack.hip).
-// Opt-in: measured slower than one launch per operator on MI355X ("persistent decode step").
-static bool stack_enabled() {
-    const char *e = getenv("OPUS_STACK");
-    return e && atoi(e) == 1;
-}
-
-// after a synchronize: did a grid barrier of the persistent kernel time out?
-static int stack_check(opus_ctx *c) {
-    if (!c->stack_used) return OPUS_OK;
-    c->stack_used = false;
-    unsigned flag = 0;
-    HIPC(hipMemcpy(&flag, c->d_bar + 2, sizeof(flag), hipMemcpyDeviceToHost));
-    if (!flag) return OPUS_OK;
-    HIPC(hipMemset(c->d_bar, 0, (1024 + 16 * 1024) * sizeof(unsigned)));
-    return fail(OPUS_EHIP, "decode stack: a grid barrier timed out (workgroups not co-resident?); results are invalid");
-}
-
 // One decode step for the token ids in d_tok (device): embeds them, runs the stack at slot T + *step,
 // leaves logits in c->d_logits and advances *step.
 static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
@@ -898,8 +896,7 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     const int ctx_cap = g.max_prompt + g.max_new_tokens;
     // batched Llama / Qwen2 step: the embedding kernel also leaves fp16(x) and its per-block sums of squares, so that the first
     // layer's QKV GEMM can take the row-scale RMSNorm form like every later one (whose producer is the previous down GEMM)
-    const bool rowscale = g.dec_arch == 0 && fuse_rows() && B > SKINNY_MAX_M && B <= MID_MAX_M && (H & 255) == 0 &&
-                          !(stack_enabled() && !g.dec_qkv_bias && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap));
+    const bool rowscale = g.dec_arch == 0 && fuse_rows() && B > SKINNY_MAX_M && B <= MID_MAX_M && (H & 255) == 0;
     // Fragment-ordered fp16 activations for the GEMMs that gemm_stream_kernel will take (gemm_stream.hip "Activation layout"):
     // the producer of each such matrix is told to write that layout - fp16(x) for the QKV projection (embedding kernel for
     // layer 0, the down projection's epilogue / reduce afterwards) and the attention output for the wo projection.
@@ -907,35 +904,12 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     const bool wo_tiled = rowscale && gemm_stream_would(B, H, QD, 0, 1, 0, c->gemm_ws_bytes);
     const bool down_tiled = rowscale && (F & 63) == 0 && gemm_stream_would(B, H, F, 0, 1, 0, c->gemm_ws_bytes);
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, rowscale ? c->d_xln : nullptr,
-                                                  rowscale ? c->d_ssq : nullptr, qkv_tiled ? 1 : 0, s));
+                                                  rowscale ? c->d_ssq : nullptr, qkv_tiled ? 1 : 0, c->cs_dec, c->d_kstart, c->d_step, T,
+                                                  hd / 2, c->cs_row, s));
     c->xln_tiled = qkv_tiled;
     c->xh_src = rowscale ? c->d_xl : nullptr;
     if (rowscale) c->ssq_nblk = H >> 8;
     if (g.dec_arch == 1) return decode_step_opt(c, s);
-    if (stack_enabled() && !g.dec_qkv_bias && decode_stack_supported(B, H, F, nh, nkv, hd, ctx_cap)) {
-        c->stack_used = true;
-        StackParams sp;
-        sp.layers = c->d_stack_layers; sp.n_layers = g.dec_layers; sp.lm_head = c->lm_head;
-        sp.B = B; sp.H = H; sp.F = F; sp.nh = nh; sp.nkv = nkv; sp.V = g.dec_vocab;
-        sp.eps = g.dec_rms_eps; sp.scale = 1.0f / sqrtf((float)hd);
-        sp.x = c->d_xl; sp.qkv = c->d_qkv; sp.ctx = c->d_ctx; sp.act = c->d_act; sp.logits = c->d_logits;
-        sp.cs = c->cs_dec; sp.kstart = c->d_kstart; sp.step = c->d_step; sp.T0 = T;
-        sp.kc = c->kc; sp.vc = c->vc; sp.cache_sl = c->cache_sl; sp.cache_sb = c->cache_sb; sp.cache_sh = c->cache_sh;
-        sp.ctx_cap = ctx_cap; sp.bar = c->d_bar;
-        sp.seg_max = sp.xs_bytes = sp.red_floats = 0;
-        sp.trace = nullptr; sp.trace_block = 0;
-        static const char *trace_env = getenv("OPUS_STACK_TRACE");     // tuning aid: workgroup id to trace
-        if (trace_env) {
-            if (!c->d_trace) { HIPC(hipMalloc(&c->d_trace, 64 * sizeof(unsigned long long))); HIPC(hipMemset(c->d_trace, 0, 64 * 8)); }
-            sp.trace = c->d_trace; sp.trace_block = atoi(trace_env);
-        }
-        // algorithmic bytes of the launch: every decoder weight once + the rows' K/V history
-        const double wbytes = 2.0 * ((double)g.dec_layers * ((double)QKV * H + (double)H * QD + 3.0 * F * H) + (double)g.dec_vocab * H);
-        const double bytes = wbytes + 4.0 * g.dec_layers * B * nkv * hd * (T + 1);
-        KLF(KC_STACK, bytes, 0.5 * wbytes * 2.0 * B, launch_decode_stack(sp, hd, s));
-        KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
-        return OPUS_OK;
-    }
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
         if (rowscale && c->xh_src == c->d_xl) {
@@ -1002,7 +976,6 @@ extern "C" int opus_llama_decode_step(opus_ctx *c, const int32_t *d_tok, float *
     int32_t st = 0;
     HIPC(hipMemcpyAsync(&st, c->d_step, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
-    OPC(stack_check(c));
     if (st >= c->cfg.max_new_tokens) return fail(OPUS_ESHAPE, "decode_step: KV cache is full (%d steps)", st);
     OPC(decode_step(c, s, d_tok));
     if (d_logits)
@@ -1025,7 +998,7 @@ static int argmax(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id
     }
     KL(KC_OTHER, 512.0 * c->cur_B,
        launch_argmax_step(c->d_pval, c->d_pidx, chosen, c->cur_B, c->d_eos, n_eos, pad_id, c->d_fin, d_out, max_new, c->d_step,
-                          c->d_next, c->d_nunf, s));
+                          c->d_next, c->d_nunf, c->d_stop, c->n_stop, s));
     return OPUS_OK;
 }
 
@@ -1060,8 +1033,7 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
     const bool use_graph = s != nullptr && !c->timing && !getenv("OPUS_NO_GRAPH");
     auto graph_matches = [&]() {
         return c->gexec && c->g_B == B && c->g_T == T && c->g_maxnew == max_new && c->g_pad == pad_id &&
-               c->g_neos == n_eos && c->g_out == d_out_ids && c->g_temp == temperature && c->g_top_p == top_p &&
-               c->g_stack == stack_enabled();
+               c->g_neos == n_eos && c->g_out == d_out_ids && c->g_temp == temperature && c->g_top_p == top_p;
     };
     const bool same_graph = graph_matches();
     std::vector<int32_t> nunf(max_new, 1);
@@ -1087,7 +1059,7 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
                 (void)hipGraphDestroy(graph);
                 if (ee != hipSuccess) { c->gexec = nullptr; return fail(OPUS_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ee)); }
                 c->g_B = B; c->g_T = T; c->g_maxnew = max_new; c->g_pad = pad_id; c->g_neos = n_eos;
-                c->g_temp = temperature; c->g_top_p = top_p; c->g_stack = stack_enabled();
+                c->g_temp = temperature; c->g_top_p = top_p;
                 c->g_out = d_out_ids;
             }
             HIPC(hipGraphLaunch(c->gexec, s));
@@ -1095,7 +1067,7 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
         produced = i + 1;
         // HF stops as soon as every row has finished; poll every 8 steps (finished rows emit pad, so
         // the ids are identical and n_out is computed exactly below).
-        if (n_eos > 0 && (i & 7) == 7) {
+        if ((n_eos > 0 || c->n_stop > 0) && (i & 7) == 7) {
             HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)(i + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIPC(hipStreamSynchronize(s));
             bool done = false;
@@ -1105,17 +1077,23 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
     }
     HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)produced * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
-    OPC(stack_check(c));
-    if (c->d_trace) {
-        unsigned long long tr[64];
-        HIPC(hipMemcpy(tr, c->d_trace, sizeof(tr), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[stack trace, us since first mark]");
-        for (int k = 0; k < 64 && tr[k]; ++k) fprintf(stderr, " %.2f", (double)(tr[k] - tr[0]) * 0.01);
-        fprintf(stderr, "\n");
-    }
     int n = produced;
     for (int k = 0; k < produced; ++k) if (nunf[k] == 0) { n = k + 1; break; }
     *n_out = n;
+    return OPUS_OK;
+}
+
+// Opt-in early stop on a token sequence ("### early-stop as an opt-in").  The reference decodes to
+// max_new_tokens and cuts the TEXT at the first "###" afterwards (eval/run_opus_ddp.py:19-27); with the ids of "###" set
+// here a row is finished as soon as its new ids end with them (later positions hold pad_id, as after an EOS), which leaves
+// the cut text unchanged and lets a batch stop early.  n = 0 clears it.  Host ids, at most 8.
+extern "C" int opus_set_stop_sequence(opus_ctx *c, const int32_t *ids, int32_t n) {
+    if (!c || n < 0 || n > 8 || (n > 0 && !ids)) return fail(OPUS_EBADARG, "set_stop_sequence: 0 <= n <= 8 ids");
+    HIPC(hipSetDevice(c->device));
+    if (n) HIPC(hipMemcpy(c->d_stop, ids, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->n_stop = n;
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // the captured step holds n_stop
+    c->g_B = -1;
     return OPUS_OK;
 }
 
@@ -1298,7 +1276,7 @@ extern "C" int opus_timing_reset(opus_ctx *c) {
     return OPUS_OK;
 }
 static const char *kclass_names[KC_COUNT] = {"gemm_skinny", "gemm_mid", "gemm_wide", "gemm_ring", "gemm_pp", "gemm_tile", "splitk_reduce",
-                                            "attn_prefill", "attn_decode", "norm", "other", "decode_stack", "gemm_stream"};
+                                            "attn_prefill", "attn_decode", "norm", "other", "gemm_stream"};
 static const char *phase_names[PH_COUNT] = {"encode", "project", "splice", "prefill", "decode", "other"};
 
 extern "C" int opus_timing_get(opus_ctx *c, const char *kernel_class, const char *phase, double *ms, int64_t *launches,

@@ -15,6 +15,12 @@
 //   combine  (m, l, O) of the 4 waves x KPN key groups through LDS, one pass.
 // The new key / value are used from LDS, so nothing depends on in-launch global visibility.
 // slot = T0 + *step is read from device memory so the same launch can be replayed from a hipGraph.
+// Latency chain (round 3).  The kernel is one wave of workgroups whose time is a chain of dependent memory round trips, not
+// bytes.  Two links are gone: (1) key tiles are indexed by ABSOLUTE cache slot (tile t = slots 32 t .. 32 t + 31, masked to
+// kstart[b] <= slot < T0 + step afterwards), so the first tile's K / V addresses depend on nothing the kernel has to load and
+// are requested at entry beside *step and kstart[b] (rows whose left padding is >= 32 slots re-request: speed only); (2) the
+// rotary (cos, sin) row of each batch row's position comes from a per-step table cs_row[b] written once per decode step by
+// the embedding kernel instead of from the position table behind (step, kstart).
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -47,27 +53,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     const int h0 = blockIdx.x * GP;                 // first query head of this workgroup
     const int kvh = h0 / G;
     const bool writer = (h0 % G) == 0;              // one workgroup per kv head appends to the cache
-    const int slot = p.T0 + *p.step;
-    const int kstart = p.kstart[b];
-    const int pos = slot - kstart;
-    const int ncached = slot - kstart;              // cached keys kstart .. slot-1; the new key comes from LDS
-    const int64_t ld = (int64_t)(p.nh + 2 * p.nkv) * HD;
     half_t *kcb = p.kc + b * p.cache_sb + kvh * p.cache_sh;
     half_t *vcb = p.vc + b * p.cache_sb + kvh * p.cache_sh;
-    const int ntiles = (ncached + 31) >> 5;
-    const int new_wave = ntiles & 3;                // the wave with the fewest tiles also takes the new key
+    const int64_t ld = (int64_t)(p.nh + 2 * p.nkv) * HD;
 
-    // ---- prefetch this wave's first tile (K fragments + V rows) before the rotary / staging phase: the dependent global
-    // round trips of the step (q/k/v row, K, V) overlap into one
+    // ---- this wave's first tile (K fragments + V rows of absolute slots 32 wave ..): requested before anything else ----
     h8 kf[2][KS], vr[KPK];
     const int dv = lane % DV, kp = lane / DV;
+    const int last_slot = p.ctx_cap - 1;
     auto load_tile = [&](int t) {
         const int j0 = 32 * t;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             int j = j0 + 16 * a + li;
-            j = j < ncached ? j : (ncached > 0 ? ncached - 1 : 0);
-            const half_t *kr = kcb + (int64_t)(kstart + j) * HD;
+            j = j < last_slot ? j : last_slot;       // (slots outside [kstart, slot) are masked in tile())
+            const half_t *kr = kcb + (int64_t)j * HD;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int d = 32 * s + 8 * g;
@@ -77,11 +77,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
         for (int i = 0; i < KPK; ++i) {
             int j = j0 + KPK * kp + i;
-            j = j < ncached ? j : (ncached > 0 ? ncached - 1 : 0);
-            vr[i] = *reinterpret_cast<const h8 *>(vcb + (int64_t)(kstart + j) * HD + dv * 8);
+            j = j < last_slot ? j : last_slot;
+            vr[i] = *reinterpret_cast<const h8 *>(vcb + (int64_t)j * HD + dv * 8);
         }
     };
-    if (wave < ntiles) load_tile(wave);
+    if (32 * wave < p.ctx_cap) load_tile(wave);
+    const int slot = p.T0 + *p.step;
+    const int kstart = p.kstart[b];
+    const int t_first = kstart >> 5;                // first tile with a visible key
+    const int t_end = (slot + 31) >> 5;             // cached keys are slots kstart .. slot-1; the new key comes from LDS
+    const int ntiles = t_end > t_first ? t_end - t_first : 0;
+    const int new_wave = ntiles & 3;                // the wave with the fewest tiles also takes the new key
 
     // ---- the new token's q / k / v (optionally: sum of the QKV GEMM's k-part slabs, RMSNorm row scale, bias), rotary on
     // the query heads and the key; stage them in LDS and append k, v to the cache ----
@@ -90,9 +96,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     // rotary pairs and of its v element.  Written as "load, add, load, add" (a runtime-length loop over slabs, stores to the
     // cache in between) this phase was a chain of ~30 dependent L2 round trips and two thirds of the kernel's time.
     float rstd = 1.0f;
+    float tq[4] = {0.f, 0.f, 0.f, 0.f};              // the row's sums of squares: 4 blocks per lane requested here, summed in stage()
     if (p.row_ssq) {
-        float q = 0.f;
-        for (int j0 = 0; j0 < p.row_nblk; j0 += 256) {            // (16-column blocks from gemm_stream_kernel: 256 of them at H = 4096)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 64 * u + lane;
+            tq[u] = p.row_ssq[(int64_t)b * p.row_nblk + (j < p.row_nblk ? j : p.row_nblk - 1)];
+            tq[u] = j < p.row_nblk ? tq[u] : 0.f;
+        }
+    }
+    auto finish_rstd = [&]() {                       // called behind the requests of stage(): one round trip for everything
+        if (!p.row_ssq) return;
+        float q = (tq[0] + tq[1]) + (tq[2] + tq[3]);
+        for (int j0 = 256; j0 < p.row_nblk; j0 += 256) {          // (more than 256 blocks: residual streams wider than 4096)
             float t[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         rstd = rsqrtf(q / (float)p.K + p.eps);
-    }
+    };
     constexpr int NE = ((GP + 1) * HALF + 255) / 256;
     auto stage = [&](auto ksn_tag) {
         constexpr int KSN = decltype(ksn_tag)::value;          // number of slabs; 0: finished fp16 projections in p.qkv
@@ -123,8 +139,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             jj[e] = ii / HALF;
             dd[e] = ii % HALF;
             const int64_t col = (jj[e] < GP ? (int64_t)(h0 + jj[e]) * HD : (int64_t)(p.nh + kvh) * HD) + dd[e];
-            cc[e] = p.cs[((int64_t)pos * HALF + dd[e]) * 2];
-            sn[e] = p.cs[((int64_t)pos * HALF + dd[e]) * 2 + 1];
+            const float2 csv = *reinterpret_cast<const float2 *>(p.cs_row + ((int64_t)b * HALF + dd[e]) * 2);
+            cc[e] = csv.x;
+            sn[e] = csv.y;
             if (KSN) {
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
@@ -146,6 +163,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         } else {
             tv[0] = (float)p.qkv[b * ld + vcol];
         }
+        finish_rstd();
         // projection output rounded to fp16, as the unfused GEMM stores it
         auto fin = [&](const float (&t)[NT], float bias) -> float {
             if (!KSN) return t[0];
@@ -217,8 +235,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
     float *myp = pw + wave * GP * 32;
 
-    // one tile of up to 32 keys: nvalid visible keys; K fragments in kf, V rows in vr
-    auto tile = [&](int nvalid) {
+    // one tile of 32 keys of which [lo, hi) are visible (lo < hi); K fragments in kf, V rows in vr
+    auto tile = [&](int lo, int hi) {
         f4 s2[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -232,13 +250,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = (16 * a + 4 * g + r) < nvalid ? s2[a][r] * p.scale : -INFINITY;
+                const int kk = 16 * a + 4 * g + r;
+                const float v = (kk >= lo && kk < hi) ? s2[a][r] * p.scale : -INFINITY;
                 s2[a][r] = v;
                 mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);        // nvalid >= 1: finite
+        const float m_new = fmaxf(m_run, mx);        // lo < hi: finite
         const float alpha = __expf(m_run - m_new);   // 0 on the first tile
         float ps = 0.f;
 #pragma unroll
@@ -247,8 +266,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // P is rounded to fp16 before the PV product, as the prefill kernel and HF (softmax .to(q.dtype))
-                const float e = __expf(s2[a][r] - m_new);
-                ps += e;
+                const float e = __expf(s2[a][r] - m_new);   // (0 for masked keys: their V rows may hold anything finite or not,
+                ps += e;                                      //  so the product below is guarded)
                 pv[r] = (float)(half_t)e;
             }
             if (li < GP) *reinterpret_cast<f4 *>(myp + li * 32 + 16 * a + 4 * g) = pv;
@@ -279,10 +298,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    for (int t = wave; t < ntiles; t += 4) {
-        if (t != wave) load_tile(t);
-        const int left = ncached - 32 * t;
-        tile(left < 32 ? left : 32);
+    for (int t = t_first + wave; t < t_end; t += 4) {
+        if (t != wave) load_tile(t);                 // (the tile requested at entry is the right one unless the row is padded by >= 32)
+        const int lo = kstart - 32 * t, hi = slot - 32 * t;
+        tile(lo > 0 ? lo : 0, hi < 32 ? hi : 32);
     }
     if (wave == new_wave) {                          // the new key / value: a one-key tile fed from LDS
 #pragma unroll
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
         for (int i = 0; i < KPK; ++i)
             vr[i] = (i == 0 && kp == 0) ? *reinterpret_cast<const h8 *>(sv + dv * 8) : h8{0, 0, 0, 0, 0, 0, 0, 0};
-        tile(1);
+        tile(0, 1);
     }
 
     // ---- publish (m, l) per head and the partial outputs; combine ----

@@ -22,7 +22,7 @@ int skinny_max_m();   // rows up to which the skinny kernel is used (default 4, 
 constexpr int MID_MAX_M = 64;   // (65..128 rows measured faster on the split-K tile kernel)
 // kernel classes of the per-launch timing (opus_timing_get): one per kernel family
 enum KClass { KC_SKINNY = 0, KC_MID, KC_WIDE, KC_RING, KC_PP, KC_TILE, KC_REDUCE, KC_ATTN_PREFILL, KC_ATTN_DECODE, KC_NORM,
-              KC_OTHER, KC_STACK, KC_STREAM, KC_COUNT };
+              KC_OTHER, KC_STREAM, KC_COUNT };
 // phases of the path a launch belongs to (set by the entry points of api.cpp)
 enum Phase { PH_ENCODE = 0, PH_PROJECT, PH_SPLICE, PH_PREFILL, PH_DECODE, PH_OTHER, PH_COUNT };
 
@@ -209,8 +209,10 @@ hipError_t launch_dec_rope_cache(half_t *qkv, const float *cs, const int32_t *ks
 hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s);
 // x[b,:] = fp32(emb[tok[b]]); optionally also the fp16 copy xh and the per-256-column sums of squares ssq[b][H/256] (the
 // producer side of the row-scale RMSNorm fusion, GemmParams::row_ssq)
+// ... and (cs != nullptr) the rotary rows of this step: cs_row[b][d] = cs[T0 + *step - kstart[b]][d], d < half (float2 each)
 hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
-                               int xh_tiled, hipStream_t s);
+                               int xh_tiled, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int half,
+                               float *cs_row, hipStream_t s);
 hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, const int32_t *step, int t0, int B, int Tq,
                           int H, int max_idx, hipStream_t s);
 hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s);
@@ -231,7 +233,7 @@ hipError_t launch_sample_select(const float *logits, int B, int V, float tempera
                                 int32_t *cand_n, float *zpart, float *spart, int32_t *chosen, hipStream_t s);
 hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, const int32_t *chosen, int B, const int32_t *eos, int n_eos, int pad_id,
                               int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
-                              int32_t *next_tok, int32_t *n_unfinished, hipStream_t s);
+                              int32_t *next_tok, int32_t *n_unfinished, const int32_t *stop, int n_stop, hipStream_t s);
 hipError_t launch_step_advance(int32_t *step, hipStream_t s);
 hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kstart, hipStream_t s);
 
@@ -248,7 +250,7 @@ struct AttnDecodeParams {
     float eps;
     int K;
     const float *bias;
-    const float *cs;            // rotary table
+    const float *cs_row;        // [B][hd / 2][2] (cos, sin) of each row's position in THIS step (written by the embedding kernel)
     const int32_t *kstart, *step;
     int T0, nh, nkv;
     half_t *kc, *vc;            // this layer's cache
@@ -259,33 +261,6 @@ struct AttnDecodeParams {
     int out_tiled = 0;          // write `out` in fragment order (tiled_off) for a GemmParams::a_tiled consumer
 };
 hipError_t launch_attn_decode(const AttnDecodeParams &p, int B, int hd, hipStream_t s);
-
-// decode_stack.hip : the whole decoder stack + lm_head of one decode step in one persistent launch (batch <= 4)
-constexpr int STACK_MAX_B = 4;
-struct StackLayer { const half_t *wqkv, *wo, *wgu, *wd; };
-struct StackParams {
-    const StackLayer *layers;   // device array [n_layers]
-    int n_layers;
-    const half_t *lm_head;
-    int B, H, F, nh, nkv, V;
-    float eps, scale;
-    float *x;                   // [B][H] fp32 residual stream (in: embedded tokens, out: last hidden state)
-    half_t *qkv, *ctx, *act;    // [B][QKV], [B][nh*hd], [B][F] scratch
-    float *logits;              // [B][V]
-    const float *cs;            // rope table
-    const int32_t *kstart, *step;
-    int T0;
-    half_t *kc, *vc;
-    int64_t cache_sl, cache_sb, cache_sh;
-    int ctx_cap;
-    unsigned *bar;              // [0] arrivals, [1] finished workgroups, [2] timeout flag, [1024 + 1024 k] go words
-                                //   (all zero between launches)
-    int seg_max, xs_bytes, red_floats;   // filled by the launcher
-    unsigned long long *trace;  // tuning aid: timeline of workgroup trace_block in layer 1 (or nullptr)
-    int trace_block;
-};
-bool decode_stack_supported(int B, int H, int F, int nh, int nkv, int hd, int ctx_cap);
-hipError_t launch_decode_stack(const StackParams &p, int hd, hipStream_t s);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -181,8 +181,15 @@ hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, co
 // RMSNorm fusion of the first layer's QKV GEMM consumes (GemmParams::row_ssq).
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__restrict__ tok, const half_t *__restrict__ emb,
                                                            int H, int V, float *__restrict__ x, half_t *__restrict__ xh,
-                                                           float *__restrict__ ssq, int xh_tiled) {
+                                                           float *__restrict__ ssq, int xh_tiled, const float *__restrict__ cs,
+                                                           const int32_t *__restrict__ kstart, const int32_t *__restrict__ step,
+                                                           int T0, int half, float *__restrict__ cs_row) {
     const int b = blockIdx.x;
+    if (cs) {   // rotary (cos, sin) row of this batch row's position in this step, for every attention launch of the step
+        const int pos = T0 + *step - kstart[b];
+        for (int d = threadIdx.x; d < half; d += 256)
+            reinterpret_cast<float2 *>(cs_row)[(int64_t)b * half + d] = reinterpret_cast<const float2 *>(cs)[(int64_t)pos * half + d];
+    }
     int id = tok[b];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
     for (int c = threadIdx.x; c < (H >> 3); c += 256) {
@@ -203,9 +210,11 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__rest
     }
 }
 hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
-                               int xh_tiled, hipStream_t s) {
+                               int xh_tiled, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int half,
+                               float *cs_row, hipStream_t s) {
     if (xh && (H & 255)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x, xh, ssq, xh_tiled);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x, xh, ssq, xh_tiled, cs, kstart, step, T0, half,
+                       cs_row);
     return hipGetLastError();
 }
 
@@ -488,7 +497,8 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(const float *__restrict
                                                          const int32_t *__restrict__ eos, int n_eos, int pad_id,
                                                          int32_t *__restrict__ finished, int32_t *__restrict__ out_ids,
                                                          int max_new, const int32_t *__restrict__ step,
-                                                         int32_t *__restrict__ next_tok, int32_t *__restrict__ n_unf) {
+                                                         int32_t *__restrict__ next_tok, int32_t *__restrict__ n_unf,
+                                                         const int32_t *__restrict__ stop, int n_stop) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float bv = pval[b * APART + lane];
     int bi = pidx[b * APART + lane];
@@ -506,6 +516,13 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(const float *__restrict
         if (st < max_new) out_ids[(int64_t)b * max_new + st] = tok;
         if (!fin)
             for (int e = 0; e < n_eos; ++e) fin |= (tok == eos[e]);
+        // opt-in stop sequence (the ids of "###", which the reference cuts at after decoding: run_opus_ddp.py:19-27): a row
+        // whose last n_stop new ids spell it is finished - what it would emit afterwards is cut from the text anyway
+        if (!fin && n_stop > 0 && st + 1 >= n_stop && st < max_new) {
+            bool hit = true;
+            for (int k = 0; k < n_stop; ++k) hit = hit && out_ids[(int64_t)b * max_new + st - n_stop + 1 + k] == stop[k];
+            fin |= hit ? 1 : 0;
+        }
         finished[b] = fin;
         next_tok[b] = tok;
         if (!fin && st < max_new) atomicAdd(&n_unf[st], 1);
@@ -513,9 +530,9 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(const float *__restrict
 }
 hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, const int32_t *chosen, int B, const int32_t *eos,
                               int n_eos, int pad_id, int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
-                              int32_t *next_tok, int32_t *n_unfinished, hipStream_t s) {
+                              int32_t *next_tok, int32_t *n_unfinished, const int32_t *stop, int n_stop, hipStream_t s) {
     hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, chosen, eos, n_eos, pad_id, finished, out_ids,
-                       max_new, step, next_tok, n_unfinished);
+                       max_new, step, next_tok, n_unfinished, stop, n_stop);
     return hipGetLastError();
 }
 

@@ -30,12 +30,13 @@ from opus_pllm_amd.prompt import after_process_output, build_prompt, max_new_tok
 
 
 def annotate(model, tokenizer, items, input_path, batch_size, max_new, temperature=0.0, top_p=0.7, num_beams=1,
-             use_input_embed=False, device=None):
+             use_input_embed=False, device=None, logits_out=None, stop_sequence=None):
     """The batch loop of run_opus_ddp.py:88-134 over this rank's items -> [n, max_new] new ids (rows padded with eos).
 
     use_input_embed (two-stage pipeline): the `input_embed` vectors of the WHOLE shard go through the modality
     projectors once, at M = len(items) (model.project_dataset), and the decode batches consume the stored protein tokens;
-    without it every batch encodes and projects its own proteins, as the reference does."""
+    without it every batch encodes and projects its own proteins, as the reference does.
+    logits_out (a list, --dump_logits): receives the fp32 [b, V] logits of each batch's last decode step (model.last_logits)."""
     dev = device or model.device
     outs = []
     prot_all = None
@@ -51,7 +52,9 @@ def annotate(model, tokenizer, items, input_path, batch_size, max_new, temperatu
         with torch.inference_mode():
             out = model.generate(ids, [q["input"] for q in batch], attention_mask=mask, pad_token_id=tokenizer.eos_token_id,
                                  do_sample=temperature > 0, temperature=temperature, top_p=top_p,
-                                 num_beams=num_beams, max_new_tokens=max_new, use_cache=True, **extra)
+                                 num_beams=num_beams, max_new_tokens=max_new, use_cache=True, stop_sequence=stop_sequence, **extra)
+        if logits_out is not None:
+            logits_out.append(model.last_logits(len(batch)))
         full = torch.full((out.shape[0], max_new), tokenizer.eos_token_id, dtype=torch.long, device=dev)
         full[:, : out.shape[1]] = out
         outs.append(full)
@@ -94,9 +97,16 @@ def eval_model(args):
                                                     max_prompt=max(args.max_prompt or 0, prompt_capacity(tok, mine, args.input_path, cfg.n_prot_tokens))))
     dev = torch.device("cuda", local)
     t0 = time.time()
+    logits = [] if args.dump_logits else None
     local_ids = annotate(model, tokenizer, mine, args.input_path, args.batch_size, max_new, args.temperature, args.top_p,
-                         args.num_beams, args.use_input_embed, dev)
+                         args.num_beams, args.use_input_embed, dev, logits,
+                         tokenizer.encode("###", add_special_tokens=False) if args.stop_at_hashes else None)
     all_ids = odist.all_gather_ids(local_ids, tokenizer.eos_token_id)
+    if logits is not None:      # parity dump: last-step fp32 logits of every item, gathered in rank order over RCCL
+        loc = torch.cat(logits) if logits else torch.empty((0, model.cfg.dec_vocab), dtype=torch.float32, device=dev)
+        all_logits = odist.all_gather_logits(loc)
+        if rank == 0:
+            torch.save(all_logits.cpu(), args.dump_logits)
     if rank == 0:
         dt = time.time() - t0
         texts = [after_process_output(t) for t in tokenizer.batch_decode(all_ids, skip_special_tokens=True)]
@@ -127,4 +137,9 @@ if __name__ == "__main__":
     p.add_argument("--collective_timeout", type=int, default=1800, help="seconds before a stuck RCCL wait aborts the run")
     p.add_argument("--use_input_embed", action="store_true",
                    help="stage 2 of the two-stage pipeline: take `input_embed` from the .jsonl instead of running ESM-2")
+    p.add_argument("--stop_at_hashes", action="store_true",
+                   help="opt-in: finish a row once it has generated the ids of '###' (the reference decodes on to max_new_tokens "
+                        "and cuts the text there afterwards: same text, less decoding)")
+    p.add_argument("--dump_logits", type=str, default=None,
+                   help="parity dump: save the fp32 last-step logits of every item ([n, V], input order) to this .pt file")
     eval_model(p.parse_args())

@@ -198,18 +198,32 @@ class OpusLlamaForCausalLM:
         self._leave()
         return emb, mo, po
 
+    PROJECT_CHUNK = 4096       # rows per projector launch of project_dataset (8H x 8H GEMM at 1.3 PFLOP/s from ~1024 rows up)
+
     def project_dataset(self, pooled: torch.Tensor) -> torch.Tensor:
         """The batched projector stage of the two-stage pipeline: pooled ESM-2 embeddings of a whole dataset
         shard fp32 [N, enc_dim] (the `input_embed` field written by generate_esm_embedding.py, consumed by the reference at
-        opus_arch.py:151-161) -> protein tokens fp16 [N, n_prot_tokens, hidden] in ONE call, i.e. the modality projectors run
-        at M = N (>= 512 for any real dataset: MFMA-bound GEMMs, processed in chunks of max(max_batch, 4096) rows) instead of
-        re-streaming their 2.5 GB of weights for every batch of 8.  Feed slices of the result to generate(protein_tokens=...)."""
+        opus_arch.py:151-161) -> protein tokens fp16 [N, n_prot_tokens, hidden], the modality projectors running at
+        M = PROJECT_CHUNK rows (MFMA-bound GEMMs) instead of re-streaming their 2.5 GB of weights for every batch of 8.
+        Every launch has the SAME shape - the last chunk is padded with zero rows - so a row's tokens (and the greedy ids that
+        follow) do not depend on the shard size, i.e. on the number of ranks the dataset is split over.
+        Feed slices of the result to generate(protein_tokens=...)."""
         x = pooled.to(self.device, torch.float32).contiguous()
-        N = x.shape[0]
+        N, C_ = x.shape[0], self.PROJECT_CHUNK
         s = self._enter()
         with torch.cuda.stream(self._stream):
             z = torch.empty((N, self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16, device=self.device)
-            _cabi.check(self._lib.opus_projector_forward(self._ctx, x.data_ptr(), N, z.data_ptr(), None, s))
+            zc = None
+            for r0 in range(0, N, C_):
+                n = min(C_, N - r0)
+                if n == C_:
+                    _cabi.check(self._lib.opus_projector_forward(self._ctx, x[r0:].data_ptr(), C_, z[r0:].data_ptr(), None, s))
+                    continue
+                xc = torch.zeros((C_, x.shape[1]), dtype=torch.float32, device=self.device)
+                xc[:n] = x[r0:]
+                zc = torch.empty((C_,) + tuple(z.shape[1:]), dtype=torch.float16, device=self.device)
+                _cabi.check(self._lib.opus_projector_forward(self._ctx, xc.data_ptr(), C_, zc.data_ptr(), None, s))
+                z[r0:] = zc[:n]
         self._leave()
         return z
 
@@ -257,6 +271,7 @@ class OpusLlamaForCausalLM:
         num_beams = int(kwargs.pop("num_beams", 1) or 1)
         max_new = int(kwargs.pop("max_new_tokens", 32))
         kwargs.pop("use_cache", None)
+        self.set_stop_sequence(kwargs.pop("stop_sequence", None))          # extension (opt-in "###" early stop), see below
         pad_id = kwargs.pop("pad_token_id", self.generation_config.pad_token_id)
         eos = kwargs.pop("eos_token_id", self.generation_config.eos_token_id)
         eos = [] if eos is None else ([int(eos)] if isinstance(eos, int) else [int(e) for e in eos])
@@ -283,6 +298,18 @@ class OpusLlamaForCausalLM:
                                 device=self.device)
             embeds, mask, _ = self._splice(inputs, attention_mask, dummy, True)
         return self._greedy(embeds, mask, max_new, eos, int(pad_id), sampler)
+
+    def set_stop_sequence(self, ids: Optional[Sequence[int]]) -> None:
+        """Opt-in early stop: a row is finished once its new ids end with `ids` (at most 8) - e.g.
+        tokenizer.encode("###", add_special_tokens=False), the marker the reference cuts the decoded text at
+        (eval/run_opus_ddp.py:19-27).  The cut text is unchanged; a batch whose rows have all stopped ends early.
+        None / empty clears it (the reference's behaviour: decode to max_new_tokens)."""
+        ids = [int(t) for t in ids] if ids is not None else []
+        if ids == getattr(self, "_stop_ids", []):
+            return
+        arr = (C.c_int32 * max(1, len(ids)))(*ids)
+        _cabi.check(self._lib.opus_set_stop_sequence(self._ctx, arr, len(ids)))
+        self._stop_ids = ids
 
     def _greedy(self, embeds, mask, max_new, eos, pad_id, sampler=None) -> torch.Tensor:
         B, T, _ = embeds.shape

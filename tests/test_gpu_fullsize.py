@@ -70,29 +70,6 @@ def test_decode_step_agrees_with_prefill_of_longer_prompt(big):
     assert torch.equal(lg1.argmax(-1), lg1_ref.argmax(-1))
 
 
-def test_persistent_decode_step_agrees_with_operator_launches(big, monkeypatch):
-    """OPUS_STACK=1 (one persistent launch per decode step) against the default one-launch-per-operator path at the
-    Llama-3-8B shape: same logits up to summation order, same greedy ids."""
-    cfg, model = big
-    seqs, ids = _inputs(cfg, 2)
-    prot = model.switch_projector_embedding(model.encode_projector_embedding(model.encode_seq2embedding(seqs)))
-    emb, mask, _ = model._splice(ids, None, prot, True)
-    tok = model.prefill_logits(emb, mask).argmax(-1)
-    ref = [model.decode_logits(tok)]
-    ref.append(model.decode_logits(ref[0].argmax(-1)))
-    monkeypatch.setenv("OPUS_STACK", "1")
-    model.prefill_logits(emb, mask)
-    got = [model.decode_logits(tok)]
-    got.append(model.decode_logits(ref[0].argmax(-1)))
-    for a, b in zip(got, ref):
-        rel = (a - b).norm() / b.norm()
-        assert float(rel) < 2e-3, float(rel)
-        assert torch.equal(a.argmax(-1), b.argmax(-1))
-    a = model.generate(ids[:1], seqs[:1], max_new_tokens=8, pad_token_id=0)
-    monkeypatch.delenv("OPUS_STACK")
-    b = model.generate(ids[:1], seqs[:1], max_new_tokens=8, pad_token_id=0)
-    assert torch.equal(a, b)
-
 
 def test_left_padding_does_not_change_a_row(big):
     """A short prompt batched with a longer one (so it is left-padded) generates the same ids as alone."""

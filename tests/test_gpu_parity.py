@@ -423,31 +423,6 @@ def test_prefill_and_decode_logits_golden(micro, gold):
         assert torch.equal(lg.argmax(-1), ref[:, s + 1].argmax(-1))
 
 
-def test_persistent_decode_step_golden(micro, gold, monkeypatch):
-    """OPUS_STACK=1: the whole decoder stack of a decode step in one persistent launch (decode_stack.hip), same golden."""
-    cfg, model, W = micro
-    monkeypatch.setenv("OPUS_STACK", "1")
-    g = gold("generate_micro")
-    emb = torch.from_numpy(g["embeds"]).half()
-    mask = torch.from_numpy(g["mask_out"]).bool()
-    ref = torch.from_numpy(g["step_logits"])
-    free = torch.from_numpy(g["free_ids"])
-    if emb.shape[0] > 4:
-        pytest.skip("persistent kernel serves batch <= 4")
-    model.prefill_logits(emb, mask)
-    for s in range(4):
-        lg = model.decode_logits(free[:, s]).cpu()
-        assert rel_l2(lg, ref[:, s + 1]) < REL_L2, s
-        assert torch.equal(lg.argmax(-1), ref[:, s + 1].argmax(-1))
-    ids, amask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
-    import json as _json, os as _os
-    seqs = _json.load(open(_os.path.join(_os.path.dirname(__file__), "golden", "generate_micro.seqs.json")))
-    N = g["free_ids"].shape[1]
-    out = model.generate(ids, seqs, attention_mask=amask, pad_token_id=int(g["pad"]), do_sample=False, max_new_tokens=N)
-    assert np.array_equal(out.cpu().numpy(), g["free_ids"])
-    out2 = model.generate(ids, seqs, attention_mask=amask, pad_token_id=int(g["pad"]), do_sample=False, max_new_tokens=N)
-    assert torch.equal(out, out2)                              # graph replay of the persistent launch
-
 
 def _check_ids(got, ref, margins):
     """bit-exact up to (excluding) each row's first step with oracle margin < MARGIN_TAU."""
@@ -483,6 +458,33 @@ def test_generate_micro_golden_ids(micro, gold, gold_dir):
     out3 = model.generate(ids, seqs, attention_mask=mask, pad_token_id=pad, do_sample=False, max_new_tokens=N,
                           use_cache=True)
     assert torch.equal(out3, out)
+
+
+def test_generate_stop_sequence_opt_in(micro, gold, gold_dir):
+    """Row N2, "### early-stop as an opt-in": with a stop sequence set, a row is finished once its new ids end with it and
+    emits pad afterwards; the ids up to and including the sequence are the free-running ones, rows that never produce it are
+    untouched, and clearing the sequence restores the reference behaviour (decode to max_new_tokens)."""
+    cfg, model, W = micro
+    g = gold("generate_micro")
+    seqs = json.load(open(os.path.join(gold_dir, "generate_micro.seqs.json")))
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    pad = int(g["pad"])
+    free = torch.from_numpy(g["free_ids"])
+    N = free.shape[1]
+    kw = dict(attention_mask=mask, pad_token_id=pad, do_sample=False, max_new_tokens=N, use_cache=True)
+    base = model.generate(ids, seqs, **kw).cpu()
+    stop = [int(base[0, 2]), int(base[0, 3])]                    # two consecutive ids row 0 really generates
+    out = model.generate(ids, seqs, stop_sequence=stop, **kw).cpu()
+    for b in range(base.shape[0]):
+        hits = [t for t in range(1, N) if [int(base[b, t - 1]), int(base[b, t])] == stop]
+        if hits:
+            t = hits[0]
+            assert torch.equal(out[b, :t + 1], base[b, :t + 1]) and bool((out[b, t + 1:] == pad).all()), (b, out[b], base[b])
+        else:
+            assert torch.equal(out[b, :out.shape[1]], base[b, :out.shape[1]])
+    assert bool((out[0, 4:] == pad).all())
+    again = model.generate(ids, seqs, **kw).cpu()                # cleared: back to the free-running ids (new graph)
+    assert torch.equal(again, base)
 
 
 def test_generate_api_errors(micro):

@@ -327,3 +327,19 @@ def test_opt_and_qwen_state_dict_mappings_roundtrip():
     assert set(gq) == set(decq) and all(torch.equal(gq[k], decq[k]) for k in decq)
     assert builder.config_from_hf(dict(model_type="qwen2", hidden_size=64, num_attention_heads=4, num_key_value_heads=2,
                                        intermediate_size=128, num_hidden_layers=2, vocab_size=96, rope_theta=1e6)).dec_qkv_bias == 1
+
+
+def test_resolve_eos_token_id(tmp_path):
+    """builder.resolve_eos_token_id: generation_config.json wins over config.json over the tokenizer (what HF's
+    from_pretrained + generate do, model/builder.py:61-65); int, list (Llama-3-Instruct) and explicit null."""
+    import json as _json
+    d = str(tmp_path)
+    assert builder.resolve_eos_token_id({}, 2, d) == 2                               # tokenizer
+    assert builder.resolve_eos_token_id({"eos_token_id": 7}, 2, d) == 7              # config.json
+    for val in (11, [128001, 128009], None):
+        with open(os.path.join(d, "generation_config.json"), "w") as f:
+            _json.dump({"eos_token_id": val, "temperature": 0.6}, f)
+        assert builder.resolve_eos_token_id({"eos_token_id": 7}, 2, d) == val
+    with open(os.path.join(d, "generation_config.json"), "w") as f:
+        _json.dump({"temperature": 0.6}, f)                                          # file without the key: config.json stands
+    assert builder.resolve_eos_token_id({"eos_token_id": 7}, 2, d) == 7
