@@ -180,6 +180,42 @@ def timed(work, a, world, rank, dev, dist, cdev, steps, warmup):
     return dt, out
 
 
+def rank_diagnostics(work, world, rank, dev, dist, cdev, steps=3):
+    """N > 1 only, untimed, after the timed region: what the one max-over-ranks number cannot say.  Every rank times `steps`
+    more steps with a device synchronize after the path and another after the id gather, so that a slow RANK (its own path
+    time stands out) can be told from a slow COLLECTIVE (the gather time stands out on every rank).  -> dict on rank 0."""
+    import torch
+    gathered = [torch.empty((work.B, work.N_new), dtype=torch.long, device=cdev) for _ in range(world)]
+    run_ms, gat_ms = [], []
+
+    def sync():
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+    dist.barrier()
+    for _ in range(steps):
+        sync()
+        t0 = time.perf_counter()
+        out = work.run()
+        sync()
+        t1 = time.perf_counter()
+        dist.all_gather(gathered, out.contiguous().to(cdev))
+        sync()
+        t2 = time.perf_counter()
+        run_ms.append(1e3 * (t1 - t0)); gat_ms.append(1e3 * (t2 - t1))
+    mine = torch.tensor([sorted(run_ms)[len(run_ms) // 2], min(gat_ms)], dtype=torch.float64, device=cdev)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    runs = sorted(float(v[0]) for v in allv)
+    # the gather of a step ends when the slowest rank arrives: its floor over the steps, then the fastest rank's view of it
+    gats = sorted(float(v[1]) for v in allv)
+    who = max(range(world), key=lambda r: float(allv[r][0]))
+    return {"steps": steps, "path_ms_per_rank": {"min": runs[0], "median": runs[world // 2], "max": runs[-1], "slowest_rank": who},
+            "id_gather_ms": {"min": gats[0], "median": gats[world // 2], "max": gats[-1]},
+            "rank_census": list(range(world)),
+            "note": "untimed diagnostic steps behind the timed region: per-rank time of the path alone (device-synchronised), and "
+                    "of the [B, N_new] id all-gather alone; near-linear scaling = value(N) ~ N x value(1) with path max ~ median"}
+
+
 # ------------------------------------------------------------------------------------------------ roofline
 HBM_CLASSES = ("gemm_skinny", "gemm_mid", "gemm_wide", "gemm_stream", "attn_decode", "splitk_reduce", "norm", "other")
 
@@ -224,9 +260,12 @@ def roofline(model, work, dev):
     res = block(ms, n, by, fl, dom_hbm)
     res.update({"kernel": f"{dom} (largest summed duration of the step: {100.0 * ms / all_ms:.0f} % of kernel time)",
                 "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "traffic": None,
-                "traffic_note": "HBM bytes from rocprofv3 PMC passes of this command are in profiles/ (r02_pmc_traffic.json); "
-                                "they are not collected inside bench.py",
+                "traffic_note": "L2<->fabric bytes from rocprofv3 PMC passes of this command, per kernel class beside these "
+                                "algorithmic bytes, are in profiles/ (r03_pmc_traffic.json, tools/pmc_summary.py); counters cannot "
+                                "be collected inside bench.py",
                 "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])},
+                "algorithmic_gb_per_step": {k: round(v[2] / 1e9, 4) for k, v in tot.items()},
+                "algorithmic_tflop_per_step": {k: round(v[3] / 1e12, 4) for k, v in tot.items() if v[3] > 0},
                 "launches": {k: v[1] for k, v in tot.items()}})
     ph_out = {}
     for ph in phases:
@@ -435,6 +474,9 @@ def main():
             if r_proj is not None:
                 res["projector_stage"] = r_proj
     if world > 1:
+        diag = rank_diagnostics(main_work, world, rank, dev, dist, cdev)
+        if rank == 0:
+            res["ranks"] = diag
         dist.barrier()
     if rank == 0 and world == 1 and not dry and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, main_work.lengths[0], main_work.n_text, N_new, B)

@@ -94,6 +94,25 @@ def test_bench_gpus2_starts_two_ranks_by_itself():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["invalid"] is True
     assert d["config"]["batch_per_gpu"] == 3 and d["scaling"] == "weak" and "c2" in d
     assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    rk = d["ranks"]                                               # the N > 1 line tells a slow rank from a slow collective
+    assert rk["rank_census"] == [0, 1] and rk["path_ms_per_rank"]["min"] <= rk["path_ms_per_rank"]["max"]
+    assert rk["id_gather_ms"]["min"] >= 0 and 0 <= rk["path_ms_per_rank"]["slowest_rank"] < 2
+
+
+def test_bench_gpus8_plumbing_dry_run():
+    """The driver's N = 8 line, plumbing only (8 CPU ranks, gloo, stub workload): self-launch, rendezvous, the sequence of
+    collectives of both workloads, the per-rank diagnostics and ONE JSON line with n_gpus = 8."""
+    import json
+    r = _run_bench(["--gpus", "8", "--batch", "2", "--steps", "2", "--warmup", "1", "--new-tokens", "3"],
+                   {"OPUS_BENCH_DRYRUN": "1", "OPUS_BENCH_BACKEND": "gloo"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["batch_per_gpu"] == 2 and d["invalid"] is True
+    assert abs(d["value"] - 8 * 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["ranks"]["rank_census"] == list(range(8))
+    assert set(d["ranks"]["path_ms_per_rank"]) == {"min", "median", "max", "slowest_rank"}
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

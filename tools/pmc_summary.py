@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes of bench.py into profiles/<tag>_pmc_traffic.json.
 
-  python tools/pmc_summary.py <read_pass_dir> <write_pass_dir> <out.json> [steps_in_run]
+  python tools/pmc_summary.py <read_pass_dir> <write_pass_dir> <out.json> [bench.json]
 
 Read pass:  --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum   (the FETCH_SIZE derived counter segfaults
             rocprofv3 on this ROCm 7.2 image; its definition is built from these request counters)
@@ -9,12 +9,29 @@ Write pass: --pmc WRITE_SIZE                                 (KiB, exact for 16-
 gfx950 correction (MI355X_MICROARCH.md "HBM"): the read-request counter tallies the 128-B requests of a
 wide coalesced stream at 64 B, i.e. FETCH_SIZE reads exactly half of the bytes -> bytes = requests * 128
 for the non-32B requests.
+With bench.json (the line of `bench.py --steps 1 --warmup 0 --no-c2`, whose roofline block lists the ALGORITHMIC bytes of
+every kernel class: weights once + activations + outputs, api.cpp gemm_any / attn_decode) the summary also gives, per
+kernel class, counter bytes / algorithmic bytes - the over-fetch beyond L2 that a reader otherwise works out by hand.
 """
 import collections
 import csv
 import glob
 import json
 import sys
+
+# kernel name prefix -> kernel class of opus_timing_get (api.cpp kclass_names)
+CLASS_OF = [("gemm_skinny", "gemm_skinny"), ("gemm_mid", "gemm_mid"), ("gemm_wide", "gemm_wide"), ("gemm_stream", "gemm_stream"),
+            ("gemm_ring", "gemm_ring"), ("gemm_pp", "gemm_pp"), ("pp_tail_reduce", "splitk_reduce"), ("gemm_tile", "gemm_tile"),
+            ("splitk_reduce", "splitk_reduce"), ("attn_prefill", "attn_prefill"), ("attn_decode", "attn_decode"),
+            ("rownorm", "norm")]
+
+
+def klass(name):
+    base = name.split("<")[0].split("::")[-1]
+    for pre, k in CLASS_OF:
+        if base.startswith(pre):
+            return k
+    return "other"
 
 
 def load(d):
@@ -37,11 +54,28 @@ def main():
         n = rcnt[(name, "TCC_EA0_RDREQ_sum")]
         fetch = (req - r32) * 128 + r32 * 32
         write = wr.get(name, {}).get("WRITE_SIZE", 0.0) * 1024
-        out[name] = {"launches": n, "fetch_bytes": fetch, "write_bytes": write,
+        out[name] = {"class": klass(name), "launches": n, "fetch_bytes": fetch, "write_bytes": write,
                      "hbm_bytes_per_launch": (fetch + write) / max(n, 1)}
-    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["fetch_bytes"])[:8]:
-        print(f"{k[:70]:70s} launches={v['launches']:6d} HBM/launch={v['hbm_bytes_per_launch']/1e6:9.2f} MB")
+    result = {"kernels": out}
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["fetch_bytes"])[:10]:
+        print(f"{k[:70]:70s} launches={v['launches']:6d} fabric/launch={v['hbm_bytes_per_launch']/1e6:9.2f} MB")
+    if len(sys.argv) > 4:
+        roof = json.loads([l for l in open(sys.argv[4]) if l.startswith("{")][-1])["roofline"]
+        alg = roof.get("algorithmic_gb_per_step", {})
+        per = collections.defaultdict(lambda: [0.0, 0])
+        for v in out.values():
+            per[v["class"]][0] += v["fetch_bytes"] + v["write_bytes"]
+            per[v["class"]][1] += v["launches"]
+        classes = {}
+        print(f"\n{'class':16s} {'launches':>9s} {'fabric GB':>10s} {'algorithmic GB':>15s} {'ratio':>6s}")
+        for k, (b, n) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+            a = alg.get(k, 0.0) * 1e9
+            classes[k] = {"launches": n, "fabric_bytes": b, "algorithmic_bytes": a, "ratio": (b / a) if a else None}
+            print(f"{k:16s} {n:9d} {b/1e9:10.3f} {a/1e9:15.3f} {(b/a if a else float('nan')):6.2f}")
+        result["classes"] = classes
+        result["note"] = ("fabric = L2<->fabric bytes (TCC_EA0 read requests, gfx950-corrected, + WRITE_SIZE): Infinity-Cache hits "
+                          "are counted; algorithmic = operands / weights once + activations + outputs (bench.py roofline block)")
+    json.dump(result, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@
 #   configs[2] (mixed lengths) and configs[4]-shape lines, and the two-stage pipeline demo under the kernel trace.
 # Raw traces are summarised on the box and deleted (gpurun copies back at most 64 MiB).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o main --output-format csv -- py
 keep_stats $OUT/stats $OUT/kernel_stats.csv &&
 OPUS_NO_GRAPH=1 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OUT/pmc_rd -o rd --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline > $OUT/pmc_rd.log 2>&1 &&
 OPUS_NO_GRAPH=1 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_wr -o wr --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline > $OUT/pmc_wr.log 2>&1 &&
-python3 tools/pmc_summary.py $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt && rm -rf $OUT/pmc_rd $OUT/pmc_wr &&
+OPUS_NO_GRAPH=1 python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline > $OUT/bench_pmc_shape.json 2> /dev/null && python3 tools/pmc_summary.py $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_traffic.json $OUT/bench_pmc_shape.json > $OUT/pmc_traffic.txt && rm -rf $OUT/pmc_rd $OUT/pmc_wr &&
 python3 bench.py --mixed-lengths --steps 5 --warmup 2 --no-cpu-baseline --no-c2 > $OUT/bench_c3.json 2> $OUT/bench_c3.log &&
 python3 bench.py --model vicuna_13b --batch 32 --residues 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-c2 > $OUT/bench_c5.json 2> $OUT/bench_c5.log &&
 rocprofv3 --kernel-trace --stats -d $OUT/stats_two_stage -o ts --output-format csv -- python3 tools/two_stage_demo.py --n 4096 > $OUT/two_stage.log 2>&1 &&
