@@ -42,8 +42,8 @@ struct Tensor {
     std::vector<int64_t> shape;
 };
 
-struct EncLayer {
-    const float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2;
+struct EncLayer {   // the LayerNorm weights are folded into wqkv / w1 and the biases bqkv / b1 at load time (weights.py);
+    const float *bqkv, *bo, *b1, *b2, *sqkv, *s1;   // sqkv / s1: column sums of the folded weights (fused LayerNorm, GemmParams::ln_*)
     const half_t *wqkv, *wo, *w1, *w2;
 };
 struct DecLayer {   // arch 0: RMSNorm weights are folded into wqkv / wgu (and dec.lnf into lm_head) at load time
@@ -75,7 +75,7 @@ struct opus_ctx {
     // workspace
     char *ws = nullptr;
     size_t ws_bytes = 0;
-    float *e_x, *e_hid, *p_pool_dummy;
+    float *e_x, *e_hid, *p_pool_dummy, *e_part, *e_stat;
     half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
     half_t *p_xn, *p_y, *p_z[2];
     float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws, *d_probs, *d_zpart, *d_spart;
@@ -109,6 +109,11 @@ struct opus_ctx {
     int rq_force_wide = 0, rq_slab_only = 0, rq_ks = 1;
     // one-shot: the next gemm() reads A / writes the fp16 copy of its output in fragment order (GemmParams::a_tiled / xh_tiled)
     int rq_a_tiled = 0, rq_xh_tiled = 0, rq_c_tiled = 0;
+    // one-shot requests, fused LayerNorm around gemm_pp_kernel (GemmParams::ln_*): producer (fp16(x) into e_xn + partials into
+    // e_part; rq_ln_done reports back) and consumer (rows scaled / shifted with e_stat and this column-sum vector)
+    bool rq_ln_produce = false;
+    int rq_ln_done = 0;
+    const float *rq_ln_colsum = nullptr;
     bool xln_tiled = false;              // d_xln currently holds fp16(x) in fragment order
     const float *xh_src = nullptr;       // fp32 buffer whose fp16 copy + sum-of-squares partials are valid
     bool use_row_scale = false;          // one-shot: the next gemm() multiplies its rows by the rstd from d_ssq
@@ -152,6 +157,8 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->e_qkv = k.take<half_t>(Me * 3 * De);
     c->e_ctx = k.take<half_t>(Me * De);
     c->e_h1 = k.take<half_t>(Me * Fe);
+    c->e_part = k.take<float>(Me * (De / 64 + 1) * 2);              // (sum x, sum x^2) per row and 64-column slab (fused LayerNorm)
+    c->e_stat = k.take<float>(Me * 2);                              // (mu, rstd) per row
     const size_t B = g.max_batch, H = g.dec_dim, SW = (size_t)g.dec_dim * g.n_prot_tokens;
     const size_t PR = B;                         // (the two-stage pipeline's big workspace is allocated on first use: ensure_proj_rows)
     c->proj_rows = (int)PR;
@@ -359,16 +366,14 @@ extern "C" int opus_weights_ready(opus_ctx *c) {
     for (int l = 0; l < g.enc_layers; ++l) {
         const std::string p = "enc." + std::to_string(l) + ".";
         EncLayer &L = c->enc[l];
-        GW(p + "ln1.w", OPUS_F32, (std::vector<int64_t>{De}), L.ln1w);
-        GW(p + "ln1.b", OPUS_F32, (std::vector<int64_t>{De}), L.ln1b);
         GW(p + "wqkv", OPUS_F16, (std::vector<int64_t>{3 * De, De}), L.wqkv);
         GW(p + "bqkv", OPUS_F32, (std::vector<int64_t>{3 * De}), L.bqkv);
+        GW(p + "sqkv", OPUS_F32, (std::vector<int64_t>{3 * De}), L.sqkv);
         GW(p + "wo", OPUS_F16, (std::vector<int64_t>{De, De}), L.wo);
         GW(p + "bo", OPUS_F32, (std::vector<int64_t>{De}), L.bo);
-        GW(p + "ln2.w", OPUS_F32, (std::vector<int64_t>{De}), L.ln2w);
-        GW(p + "ln2.b", OPUS_F32, (std::vector<int64_t>{De}), L.ln2b);
         GW(p + "w1", OPUS_F16, (std::vector<int64_t>{Fe, De}), L.w1);
         GW(p + "b1", OPUS_F32, (std::vector<int64_t>{Fe}), L.b1);
+        GW(p + "s1", OPUS_F32, (std::vector<int64_t>{Fe}), L.s1);
         GW(p + "w2", OPUS_F16, (std::vector<int64_t>{De, Fe}), L.w2);
         GW(p + "b2", OPUS_F32, (std::vector<int64_t>{De}), L.b2);
     }
@@ -478,6 +483,9 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     c->rq_ks = 1;
     p.force_wide = c->rq_force_wide; p.slab_only = c->rq_slab_only; p.ks_out = &c->rq_ks;
     c->rq_force_wide = c->rq_slab_only = 0;
+    c->rq_ln_done = 0;
+    if (c->rq_ln_produce) { p.xh_out = c->e_xn; p.ssq_out = nullptr; p.ln_part = c->e_part; p.ln_done = &c->rq_ln_done; c->rq_ln_produce = false; }
+    if (c->rq_ln_colsum) { p.ln_stat = c->e_stat; p.ln_colsum = c->rq_ln_colsum; c->rq_ln_colsum = nullptr; }
     p.a_tiled = c->rq_a_tiled; p.xh_tiled = c->rq_xh_tiled; p.c_tiled = c->rq_c_tiled;
     c->rq_a_tiled = c->rq_xh_tiled = c->rq_c_tiled = 0;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
@@ -583,9 +591,24 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
     const int D = g.enc_dim, F = g.enc_ffn, nh = g.enc_heads, hd = D / nh;
     const int M = B * T;
     KL(KC_OTHER, 4.0 * M * D, launch_esm_embed(d_tokens, c->enc_emb, B, T, D, c->e_x, s));
+    // Pre-LN blocks with the LayerNorm fused around the big tiled GEMM (GemmParams::ln_*): the epilogue that writes
+    // the residual stream (wo, fc2) also leaves fp16(x) and per-row partial sums, a small kernel turns those into (mu, rstd),
+    // and the consuming projection (fc1, the next layer's QKV) runs on fp16(x) as it stands and applies
+    // rstd (acc - mu s) + c2 in its epilogue - no pass over the fp32 stream in between.  Shapes the big kernel does not take
+    // (few rows), the first layer, and OPUS_NO_LN_FUSION=1 use the stand-alone normalisation (x - mu) rstd (the affine part
+    // lives in the folded weights either way).
+    static const bool no_ln_fusion = getenv("OPUS_NO_LN_FUSION") != nullptr;   // A/B aid
+    const bool qkv_pp = !no_ln_fusion && (D & 255) == 0 && gemm_goes_pp(M, 3 * D);
+    const bool fc1_pp = !no_ln_fusion && (D & 255) == 0 && gemm_goes_pp(M, F);
+    bool have_stat = false;                        // e_xn = fp16(x), e_stat = (mu, rstd) of the current residual stream
+    auto finalize = [&]() -> int {
+        KL(KC_NORM, 8.0 * M * (D / 64) + 8.0 * M, launch_ln_finalize(c->e_part, M, D / 64, D, g.enc_ln_eps, c->e_stat, s));
+        return OPUS_OK;
+    };
     for (int l = 0; l < g.enc_layers; ++l) {
         const EncLayer &L = c->enc[l];
-        KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, L.ln1w, L.ln1b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
+        if (have_stat && qkv_pp) c->rq_ln_colsum = L.sqkv;
+        else KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, nullptr, nullptr, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
         // q <- rotary(q * hd^-0.5), k <- rotary(k): in the projection's epilogue when the big tiled kernel takes it (head_dim 64),
         // else by the stand-alone kernel on the stored projection (same arithmetic)
         if (hd == 64) {
@@ -603,10 +626,16 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
         a.kstart = nullptr; a.kend = d_lens;
         a.B = B; a.T = T; a.heads = nh; a.group = 1; a.head_dim = hd; a.causal = 0; a.scale = 1.0f;
         KLF(KC_ATTN_PREFILL, 8.0 * M * D, 4.0 * B * (double)T * T * D, launch_attn_prefill(a, s));
+        c->rq_ln_produce = fc1_pp;
         OPC(gemm(c, s, c->e_ctx, D, L.wo, M, D, D, L.bo, EPI_NONE, c->e_x, c->e_x, D, 1));
-        KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, L.ln2w, L.ln2b, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
+        have_stat = c->rq_ln_done != 0;
+        if (have_stat) { OPC(finalize()); c->rq_ln_colsum = L.s1; }
+        else KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, nullptr, nullptr, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
         OPC(gemm(c, s, c->e_xn, D, L.w1, M, F, D, L.b1, EPI_GELU, nullptr, c->e_h1, F, 0));
+        c->rq_ln_produce = qkv_pp && l + 1 < g.enc_layers;
         OPC(gemm(c, s, c->e_h1, F, L.w2, M, D, F, L.b2, EPI_NONE, c->e_x, c->e_x, D, 1));
+        have_stat = c->rq_ln_done != 0;
+        if (have_stat) OPC(finalize());
     }
     KL(KC_NORM, 8.0 * M * D, launch_layernorm(c->e_x, c->enc_lnfw, c->enc_lnfb, g.enc_ln_eps, M, D, nullptr, c->e_hid, s));
     KL(KC_OTHER, 4.0 * M * D, launch_masked_mean(c->e_hid, d_lens, B, T, D, d_pooled, s));

@@ -120,6 +120,17 @@ struct GemmParams {
     // element (row, k) of an [rows, K] matrix at tiled_off(row, k, K).  a_tiled: A is stored that way (gemm_stream_kernel only);
     // xh_tiled / c_tiled: write xh_out / the fp16 output C that way (for a consumer that will read it with a_tiled).
     int a_tiled = 0, xh_tiled = 0, c_tiled = 0;
+    // LayerNorm fused around the big tiled GEMM (gemm_pp_kernel; the encoder's pre-LN blocks).  With the norm
+    // weight folded into the consumer's weight W' = W diag(gamma) and beta into its bias c2 = W beta + b,
+    //   LN(x) W^T + b  =  rstd (x W'^T - mu s) + c2,   s[n] = sum_k W'[n][k]:
+    //  producer side (fp32 output + residual, EPI_NONE, N % 256 == 0): the epilogue also writes fp16(x) to xh_out (row-major)
+    //   and, per row and 64-column slab, (sum x, sum x^2) to ln_part[(m * N/64 + slab) * 2]; sets *ln_done;
+    //  consumer side (fp16 output, EPI_NONE / GELU): A is fp16(x) as it stands, ln_stat[m] = (mu, rstd), ln_colsum = s,
+    //   bias = c2; the epilogue applies the affine form above before the activation / the fused rotary.
+    float *ln_part = nullptr;
+    int *ln_done = nullptr;
+    const float *ln_stat = nullptr;
+    const float *ln_colsum = nullptr;
     int no_rot = 0;               // A/B aid (OPUS_NO_KROT): weight-streaming kernels walk k from chunk 0 in every workgroup
     long long *trace = nullptr;   // tuning aid (OPUS_PP_TRACE): gemm_pp_kernel writes 4 wall-clock stamps per workgroup
 };
@@ -186,12 +197,15 @@ __device__ __forceinline__ void block_row_rstd(const float *__restrict__ ssq, in
         if (lane == 0 && row < ROWS) out[row] = rsqrtf(q * inv_k + eps);
     }
 }
-bool gemm_goes_wide(int M, int N);   // would launch_gemm route an fp16-A GEMM of this shape to gemm_wide_kernel?
+bool gemm_goes_wide(int M, int N);
+bool gemm_goes_pp(int M, int N);     // would launch_gemm route an fp16-A GEMM of this shape to gemm_pp_kernel (the big tiled kernel)?   // would launch_gemm route an fp16-A GEMM of this shape to gemm_wide_kernel?
 hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s);
 
 // norm.hip
 hipError_t launch_layernorm(const float *x, const float *w, const float *b, float eps, int64_t rows, int D,
-                            half_t *out_h, float *out_f, hipStream_t s);
+                            half_t *out_h, float *out_f, hipStream_t s);   // (w == b == nullptr: (x - mu) rstd, no affine part)
+// (mu, rstd) per row from the per-slab (sum x, sum x^2) partials the LayerNorm-producing GEMM epilogue left (GemmParams::ln_part)
+hipError_t launch_ln_finalize(const float *part, int64_t rows, int nslab, int D, float eps, float *stat, hipStream_t s);
 hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t rows, int D, half_t *out,
                           hipStream_t s);
 hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s);

@@ -954,7 +954,8 @@ __host__ __device__ __forceinline__ void pp_tile_coords(int id, int tiles_m, int
     tm = grp * GM + rem_id % rows_here;
     tn = rem_id / rows_here;
 }
-template <int EPI>
+// LNA: consumer side of the fused LayerNorm (GemmParams::ln_stat / ln_colsum): y = rstd (acc - mu s) + c2 in the epilogue
+template <int EPI, bool LNA = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m, int tiles_n, int full_tiles, int tail_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HT = 16384;
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     float bz[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) bz[q] = 0.f;
-    if (p.bias) {
+    if (p.bias && !LNA) {
         if (EPI == EPI_SILU_GU16) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
@@ -1189,6 +1190,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bz[j * 4 + r] = p.bias[n0 + wc * 64 + j * 16 + 4 * g + r];
         }
+    }
+    // fused LayerNorm, consumer side: the bias c2 and the column sums s of the folded weight for this wave's 64 columns are
+    // kept in LDS behind the two patch images (32 persistent registers otherwise: the kernel is at the 256-register limit),
+    // and - per pair of row tiles, requested one pair ahead like the residual rows - (mu, rstd) of this lane's row of each tile
+    float *cb = patch + 2048;                                         // [bias 64 | colsum 64] floats
+    float2 lst[2][2];
+    auto load_stat = [&](int i, float2 &st) {
+        int m = m0 + wr * 128 + i * 16 + li;
+        m = m < p.M ? m : p.M - 1;
+        st = reinterpret_cast<const float2 *>(p.ln_stat)[m];
+    };
+    if constexpr (LNA) {
+        cb[lane] = p.bias ? p.bias[n0 + wc * 64 + lane] : 0.f;
+        cb[64 + lane] = p.ln_colsum[n0 + wc * 64 + lane];
+        load_stat(0, lst[0][0]);
+        load_stat(1, lst[0][1]);
     }
     // residual pieces of one row tile: fp32 output - 16 / RPP passes of one float4; fp16 output - 16 / RPP passes of two
     constexpr int LPR32 = NO / 4, RPP32 = 64 / LPR32, LPR16 = NO / 8, RPP16 = 64 / LPR16;
@@ -1252,6 +1269,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
 #pragma unroll
             for (int u = 0; u < RB; ++u) load_cs((ib + 1) * RB + u, rbuf[(ib + 1) & 1][u]);
         }
+        if constexpr (LNA) {
+            if (ib + 1 < 8 / RB) {
+                load_stat((ib + 1) * RB, lst[(ib + 1) & 1][0]);
+                load_stat((ib + 1) * RB + 1, lst[(ib + 1) & 1][1]);
+            }
+        }
         // 1. bias / activation in registers, 4 columns per lane -> patch image u, row li
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
@@ -1272,9 +1295,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f4 v = acc[i][j];
+                    f4 b4 = f4{0.f, 0.f, 0.f, 0.f}, c4 = b4;
+                    if constexpr (LNA) {
+                        b4 = *reinterpret_cast<const f4 *>(cb + j * 16 + 4 * g);
+                        c4 = *reinterpret_cast<const f4 *>(cb + 64 + j * 16 + 4 * g);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[r] += bz[j * 4 + r];
+                        if constexpr (LNA) v[r] = __builtin_fmaf(lst[ib & 1][u].y, v[r] - lst[ib & 1][u].x * c4[r], b4[r]);
+                        else v[r] += bz[j * 4 + r];
                         if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
                     }
                     *reinterpret_cast<f4 *>(pu + pidx(li, j * 16 + 4 * g)) = v;
@@ -1302,6 +1331,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                         const float4 rr = rcur[ps];
                         v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + nw0 + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                    if (p.ln_part) {   // fused LayerNorm, producer side (wave-uniform): fp16(x) + this slab's (sum x, sum x^2) of the row
+                        if (m < p.M)
+                            *reinterpret_cast<h4 *>(p.xh_out + (int64_t)m * p.N + nw0 + c) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                        for (int o = 1; o < LPR32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                        if (m < p.M && (lane % LPR32) == 0)
+                            reinterpret_cast<float2 *>(p.ln_part)[(int64_t)m * (p.N >> 6) + (nw0 >> 6)] = make_float2(s1, s2);
                     }
                 }
             } else {
@@ -1341,9 +1380,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                         const int m = mrow0 + r;
                         f4 lo = *reinterpret_cast<const f4 *>(pu + pidx(r, c)), hi = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 4));
                         if (m < p.M) {
-                            const float4 r0 = rcur[2 * ps], r1 = rcur[2 * ps + 1];
-                            lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
-                            hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
+                            if constexpr (!LNA) {                    // (the LayerNorm consumer form has no residual)
+                                const float4 r0 = rcur[2 * ps], r1 = rcur[2 * ps + 1];
+                                lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
+                                hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
+                            }
                             *reinterpret_cast<h8 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c) =
                                 h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
                         }
@@ -1381,6 +1422,13 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
         }
     }
     constexpr int RW = 8;                                            // rows per wave
+    // fused LayerNorm, consumer side (GemmParams::ln_stat): column sums of this lane's 4 columns, (mu, rstd) per row below
+    f4 csum = f4{0.f, 0.f, 0.f, 0.f};
+    if (p.ln_stat) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (n + c < p.N) csum[c] = p.ln_colsum[n + c];
+    }
     f4 v[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) v[i] = f4{0.f, 0.f, 0.f, 0.f};
@@ -1425,9 +1473,11 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
             no = ((n >> 5) << 4) + (n & 15);
             live = live && gate_lane && n + 16 < p.N;
         } else {
+            float2 st = make_float2(0.f, 1.f);
+            if (p.ln_stat) st = reinterpret_cast<const float2 *>(p.ln_stat)[m < p.M ? m : p.M - 1];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                x[c] += bias4[c];
+                x[c] = p.ln_stat ? __builtin_fmaf(st.y, x[c] - st.x * csum[c], bias4[c]) : x[c] + bias4[c];
                 if (EPI == EPI_GELU) x[c] = gelu_erf(x[c]);
             }
             live = live && n < p.N;
@@ -1458,8 +1508,20 @@ template <int EPI>
 static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
     if (p_in.row_ssq) return hipErrorInvalidValue;                    // no row scale in this kernel's epilogue
     GemmParams p = p_in;
+    // fused LayerNorm (GemmParams::ln_*): the consumer form must be honoured (the caller handed over un-normalised rows),
+    // the producer form is best effort (*ln_done reports it)
+    const bool lna = p.ln_stat != nullptr;
+    if (lna && (EPI == EPI_SILU_GU16 || !p.ln_colsum || p.out_f32 || p.residual || (p.N & 255) || (p.ldc & 7))) return hipErrorInvalidValue;
+    const bool lnp = p.ln_part && p.xh_out && p.ln_done && EPI == EPI_NONE && p.out_f32 && (p.N & 255) == 0 && (p.ldc & 7) == 0 &&
+                     (p.ldr & 3) == 0 && p.residual;
+    if (lnp) *p.ln_done = 1;
+    else p.ln_part = nullptr;
+    void (*kern)(GemmParams, int, int, int, int) = gemm_pp_kernel<EPI, false>;
+    if constexpr (EPI != EPI_SILU_GU16) {
+        if (lna) kern = gemm_pp_kernel<EPI, true>;
+    }
     const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);
-    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_pp_kernel<EPI>), 8 * 16384);
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(kern), 8 * 16384);
     if (ea != hipSuccess) return ea;
     // tail split: when the last round of 256 workgroups would be at most half full, its tiles are cut into k-parts that fill it
     const int T = bm * bn, KT = p.K >> 6;
@@ -1472,7 +1534,7 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
     if (rope) *p.rope_done = 1;
     else p.rope_cs = nullptr;
     const int R = T % 256;
-    if (!no_tail && !rope && p.ws && T > 256 && R > 0 && R <= 128) {
+    if (!no_tail && !rope && !lnp && p.ws && T > 256 && R > 0 && R <= 128) {   // (rope / LayerNorm-producing epilogues run in gemm_pp_kernel only)
         int sp = 256 / R;
         sp = sp > 8 ? 8 : sp;
         if (sp > KT / 4) sp = KT / 4;                                 // at least 4 k-tiles per part (pipeline prologue)
@@ -1488,7 +1550,7 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
         if (tb && nwg <= (1 << 16)) {
             GemmParams q = p;
             q.trace = tb;
-            hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(nwg), dim3(512), 8 * 16384, s, q, bm, bn, full, split);
+            hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), 8 * 16384, s, q, bm, bn, full, split);
             (void)hipStreamSynchronize(s);
             std::vector<long long> h((size_t)nwg * 4);
             (void)hipMemcpy(h.data(), tb, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -1509,7 +1571,7 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
             }
         }
     }
-    OPUS_LAUNCH(KC_PP, (gemm_pp_kernel<EPI>), dim3(full + tail * split), dim3(512), 8 * 16384, s, p, bm, bn, full, split);
+    OPUS_LAUNCH(KC_PP, kern, dim3(full + tail * split), dim3(512), 8 * 16384, s, p, bm, bn, full, split);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || split == 1) return e;
     if (tl_launch_ev) tl_launch_ev->aux_bytes = ((double)tail * split * 65536 * 4) + (double)tail * 65536 * (p.out_f32 ? 4 : 2);
@@ -2064,7 +2126,15 @@ hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass) {
     q.no_rot = 1;
     return launch_gemm_(q, s, klass);
 }
+static bool pp_min_tiles_ok(int M, int N) {
+    static const bool no_big = getenv("OPUS_NO_BIG_GEMM") != nullptr, no_pp = getenv("OPUS_NO_PP") != nullptr;   // A/B aids
+    static const int min_tiles = getenv("OPUS_PP_MIN_TILES") ? atoi(getenv("OPUS_PP_MIN_TILES")) : 128;
+    return !no_big && !no_pp && (int64_t)cdiv(M, 256) * cdiv(N, 256) >= min_tiles;
+}
+bool gemm_goes_pp(int M, int N) { return M > 96 && pp_min_tiles_ok(M, N); }
+
 static hipError_t launch_gemm_(const GemmParams &p, hipStream_t s, int *klass) {
+    if (p.ln_stat && !gemm_goes_pp(p.M, p.N)) return hipErrorInvalidValue;   // only gemm_pp_kernel applies the fused LayerNorm
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 63) || (p.lda & 7)) return hipErrorInvalidValue;
     if (p.epi == EPI_SILU_GU16 && (p.N & 31)) return hipErrorInvalidValue;
     const bool skinny = p.M <= SKINNY_MAX_M;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
             y.x = (v[i].x - mean) * rstd; y.y = (v[i].y - mean) * rstd;
             y.z = (v[i].z - mean) * rstd; y.w = (v[i].w - mean) * rstd;
             if (MODE != 2 && w) { const float4 ww = wr[c]; y.x *= ww.x; y.y *= ww.y; y.z *= ww.z; y.w *= ww.w; }
-            if (MODE == 0) { const float4 bv = br[c]; y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w; }
+            if (MODE == 0 && b) { const float4 bv = br[c]; y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w; }
             if (out_h) {
                 h4 o = {(half_t)y.x, (half_t)y.y, (half_t)y.z, (half_t)y.w};
                 reinterpret_cast<h4 *>(out_h + row * D)[c] = o;
@@ -97,6 +97,33 @@ hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t row
 }
 hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s) {
     return launch_rownorm<2>(x, nullptr, nullptr, 0.f, rows, D, out, nullptr, s);
+}
+
+// (mu, rstd) of every row from the per-64-column (sum x, sum x^2) partials of the LayerNorm-producing GEMM epilogue
+// (GemmParams::ln_part), summed in slab order.  var = E[x^2] - mu^2 in fp32 (clamped at 0): the residual streams this serves
+// have |mu| of the order of the standard deviation or below, where the cancellation costs a few ulps of the variance.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restrict__ part, int64_t rows, int nslab, float inv_d,
+                                                          float eps, float2 *__restrict__ stat) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    const float2 *src = part + m * nslab;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j0 = 0; j0 < nslab; j0 += 8) {                          // 8 partials requested at a time, added in slab order
+        float2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[j0 + u < nslab ? j0 + u : nslab - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u < nslab) { s1 += t[u].x; s2 += t[u].y; }
+    }
+    const float mu = s1 * inv_d;
+    const float var = fmaxf(s2 * inv_d - mu * mu, 0.f);
+    stat[m] = make_float2(mu, rsqrtf(var + eps));
+}
+hipError_t launch_ln_finalize(const float *part, int64_t rows, int nslab, int D, float eps, float *stat, hipStream_t s) {
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(part), rows, nslab,
+                       1.0f / (float)D, eps, reinterpret_cast<float2 *>(stat));
+    return hipGetLastError();
 }
 
 // fp32 -> fp16 cast (the identity protein projector of opus_arch.py:70-80 hands the pooled fp32 embedding straight to the

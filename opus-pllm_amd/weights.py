@@ -5,8 +5,9 @@ Replaces the state-dict loading of load_pretrained_model / initialize_protein_mo
 library borrows the pointers through opus_bind_weight.
 
 Fused tensors (fp16 GEMM weights [out, in] = nn.Linear orientation, fp32 vectors):
-  enc.emb [33,De] (row-major gather table) | enc.{l}.ln1.{w,b} | enc.{l}.wqkv [3De,De] = [q;k;v] rows,
-  enc.{l}.bqkv [3De] | enc.{l}.wo,bo | enc.{l}.ln2.{w,b} | enc.{l}.w1,b1 | enc.{l}.w2,b2 | enc.lnf.{w,b}
+  enc.emb [33,De] (row-major gather table) | enc.{l}.wqkv [3De,De] = [q;k;v] rows diag(ln1.weight),
+  enc.{l}.bqkv [3De] = [q;k;v] bias + W ln1.bias, enc.{l}.sqkv = row sums of the folded wqkv | enc.{l}.wo,bo |
+  enc.{l}.w1 = fc1 diag(ln2.weight), b1 = fc1.bias + W ln2.bias, s1 | enc.{l}.w2,b2 | enc.lnf.{w,b}
   proj.{w,b} | sw.{i}.{w,b}
   dec.emb [V,H] (row-major gather table) | dec.{l}.wqkv [(nh+2nkv)hd,H] | dec.{l}.wo
   dec.{l}.wgu [2F,H]: 32-row groups = [16 gate rows | 16 up rows] so that a 16-column MFMA tile of
@@ -17,7 +18,11 @@ Two load-time transforms make the hot loop a pure stream:
     csrc/gemm.hip): one wave-wide 16-B load = 1 KB of contiguous HBM = one MFMA operand;
   * the decoder's RMSNorm weights are FOLDED into the projection that consumes the normalised
     activations (wqkv <- wqkv diag(input_norm), wgu <- wgu diag(post_norm), lm_head <- lm_head diag(norm)),
-    fp32 product rounded once to fp16, so the kernels only need 1/rms(x) (computed in the GEMM prologue).
+    fp32 product rounded once to fp16, so the kernels only need 1/rms(x) (computed in the GEMM prologue);
+  * the encoder's pre-LayerNorms are folded the same way, LN(x) W^T + b = rstd (x W'^T - mu s) + c2 with W' = W diag(gamma),
+    s[n] = sum_k W'[n][k] (of the ROUNDED W', so that the mean cancels exactly) and c2 = W beta + b in fp32: the kernels need
+    (mu, rstd) per row only, either applied in the GEMM epilogue (csrc/gemm.hip gemm_pp_kernel, GemmParams::ln_*) or by the
+    stand-alone normalisation (x - mu) rstd in front of a plain GEMM with bias c2.
 """
 from __future__ import annotations
 
@@ -50,7 +55,11 @@ class Fused:
     shape: Tuple[int, ...]
     parts: Tuple[Part, ...]
     tiled: bool = False          # GEMM weight stored panel-tiled
-    fold: Optional[str] = None   # canonical RMSNorm weight multiplied into the columns
+    fold: Optional[str] = None   # canonical norm weight multiplied into the columns
+    # derived fp32 vectors of a folded LayerNorm (see the module docstring):
+    #   ("colsum", fused weight name)                       s[n] = sum_k W'[n][k] of the folded, rounded weight
+    #   ("bias_fold", fused weight name, canonical LN bias)  parts (the Linear bias) + W beta, W the UNFOLDED weight
+    derive: Optional[Tuple[str, ...]] = None
 
 
 def _cat(name, f16, cols, pieces: List[Tuple[str, int]], tiled=False, fold=None) -> Fused:
@@ -72,12 +81,16 @@ def fused_spec(cfg: OpusConfig) -> List[Fused]:
     tab("enc.emb", "enc.embed_tokens", cfg.enc_vocab, De)
     for l in range(cfg.enc_layers):
         s, d = f"enc.layers.{l}.", f"enc.{l}."
-        vec(d + "ln1.w", s + "ln1.weight", De); vec(d + "ln1.b", s + "ln1.bias", De)
-        out.append(_cat(d + "wqkv", True, De, [(s + "q.weight", De), (s + "k.weight", De), (s + "v.weight", De)], True))
-        out.append(_cat(d + "bqkv", False, 1, [(s + "q.bias", De), (s + "k.bias", De), (s + "v.bias", De)]))
+        out.append(_cat(d + "wqkv", True, De, [(s + "q.weight", De), (s + "k.weight", De), (s + "v.weight", De)], True,
+                        s + "ln1.weight"))
+        bq = _cat(d + "bqkv", False, 1, [(s + "q.bias", De), (s + "k.bias", De), (s + "v.bias", De)])
+        out.append(Fused(bq.name, False, bq.shape, bq.parts, derive=("bias_fold", d + "wqkv", s + "ln1.bias")))
+        out.append(Fused(d + "sqkv", False, (3 * De,), (), derive=("colsum", d + "wqkv")))
         mat(d + "wo", s + "o.weight", De, De); vec(d + "bo", s + "o.bias", De)
-        vec(d + "ln2.w", s + "ln2.weight", De); vec(d + "ln2.b", s + "ln2.bias", De)
-        mat(d + "w1", s + "fc1.weight", Fe, De); vec(d + "b1", s + "fc1.bias", Fe)
+        mat(d + "w1", s + "fc1.weight", Fe, De, s + "ln2.weight")
+        b1 = _cat(d + "b1", False, 1, [(s + "fc1.bias", Fe)])
+        out.append(Fused(b1.name, False, b1.shape, b1.parts, derive=("bias_fold", d + "w1", s + "ln2.bias")))
+        out.append(Fused(d + "s1", False, (Fe,), (), derive=("colsum", d + "w1")))
         mat(d + "w2", s + "fc2.weight", De, Fe); vec(d + "b2", s + "fc2.bias", De)
     vec("enc.lnf.w", "enc.ln_f.weight", De); vec("enc.lnf.b", "enc.ln_f.bias", De)
     if cfg.has_protein_projector:
@@ -170,8 +183,11 @@ class DeviceWeights:
             v = torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
             return v.to(self.device).to(dtype)
 
+        spec = fused_spec(cfg)
+        wanted = {f.derive[1] for f in spec if f.derive and f.derive[0] == "bias_fold"}
+        unfolded: Dict[str, torch.Tensor] = {}
         with torch.cuda.device(self.device):
-            for f in fused_spec(cfg):
+            for f in spec:
                 t = self._alloc(f)
                 t2 = t.view(t.shape[0], -1)
                 for p in f.parts:
@@ -183,12 +199,29 @@ class DeviceWeights:
                         _cabi.check(lib.opus_lora_merge(src.data_ptr(), A.data_ptr(), B.data_ptr(), float(alpha) / float(r),
                                                         p.rows, p.cols, int(r), torch.cuda.current_stream().cuda_stream))
                     t2[_dst_rows(p, self.device)] = src
+                if f.name in wanted:
+                    unfolded[f.name] = t.float()
                 if f.fold is not None:
                     t.copy_((t.float() * get(f.fold, torch.float32)[None, :]).half())
                 if f.tiled:
                     self.tensors[f.name] = tile_weight(t)
+            self._derive(spec, lambda name: unfolded[name], lambda canon_name: get(canon_name, torch.float32))
             torch.cuda.synchronize(self.device)
         return self
+
+    def _derive(self, spec, unfolded, vector) -> None:
+        """The derived vectors of the folded LayerNorms (Fused.derive): unfolded(name) -> fp32 [N, K] row-major weight before
+        the fold, vector(canonical name) -> fp32 vector."""
+        for f in spec:
+            if not f.derive:
+                continue
+            t = self.tensors[f.name]
+            if f.derive[0] == "colsum":
+                t.copy_(untile_weight(self.tensors[f.derive[1]]).float().sum(dim=1))
+            elif f.derive[0] == "bias_fold":
+                t.add_(unfolded(f.derive[1]) @ vector(f.derive[2]))
+            else:
+                raise ValueError(f.derive)
 
     @classmethod
     def synthetic(cls, cfg: OpusConfig, seed: int, device, stream: int = 0) -> "DeviceWeights":
@@ -196,8 +229,30 @@ class DeviceWeights:
         self = cls(cfg, torch.device(device))
         lib = _cabi.lib()
         spec = {n: (sh, std, mean) for n, sh, std, mean in synth.canonical_spec(cfg)}
-        with torch.cuda.device(self.device):
-            for f in fused_spec(cfg):
+        fspec = fused_spec(cfg)
+        by_name = {f.name: f for f in fspec}
+
+        def fill(t, f16, p: Part, tiled, fold=(0, 0.0, 0.0)):
+            _, std, mean = spec[p.canon]
+            _cabi.check(lib.opus_fill_synth(t.data_ptr(), _cabi.OPUS_F16 if f16 else _cabi.OPUS_F32, p.rows, p.cols,
+                                            synth.tensor_seed(p.canon, seed), std, mean, p.rb, p.rs, p.ro, 1 if tiled else 0,
+                                            fold[0], fold[1], fold[2], stream))
+
+        def unfolded(name):          # the fused weight `name` before the fold, row-major fp32 (a temporary of at most a few MB)
+            f = by_name[name]
+            tmp = torch.empty(f.shape, dtype=torch.float16, device=self.device)
+            for p in f.parts:
+                fill(tmp, True, p, False)
+            return tmp.float()
+
+        def vector(canon_name):
+            sh, _, _ = spec[canon_name]
+            tmp = torch.empty(sh, dtype=torch.float32, device=self.device)
+            fill(tmp, False, Part(canon_name, int(sh[0]), 1, int(sh[0]), int(sh[0]), 0), False)
+            return tmp
+
+        with torch.cuda.device(self.device), torch.cuda.stream(torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()):
+            for f in fspec:
                 t = self._alloc(f)
                 fseed, fstd, fmean = 0, 0.0, 0.0
                 if f.fold is not None:
@@ -208,6 +263,7 @@ class DeviceWeights:
                     _cabi.check(lib.opus_fill_synth(t.data_ptr(), _cabi.OPUS_F16 if f.f16 else _cabi.OPUS_F32,
                                                     p.rows, p.cols, synth.tensor_seed(p.canon, seed), std, mean,
                                                     p.rb, p.rs, p.ro, 1 if f.tiled else 0, fseed, fstd, fmean, stream))
+            self._derive(fspec, unfolded, vector)
         return self
 
     # -- binding ---------------------------------------------------------------------------------

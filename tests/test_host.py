@@ -119,8 +119,14 @@ def test_fused_spec_covers_every_canonical_tensor_once():
                 seen.append(p.canon)
                 assert int(np.prod(canon[p.canon])) == p.rows * p.cols
                 rows += p.rows
+            if f.derive and f.derive[0] == "colsum":      # row sums of a folded weight: no canonical source of its own
+                assert not f.parts and f.shape == (next(g for g in fused_spec(cfg) if g.name == f.derive[1]).shape[0],)
+                continue
             assert rows == f.shape[0]
-            if f.fold:                       # RMSNorm weight folded into this projection's columns
+            if f.derive:                     # ("bias_fold", weight, LayerNorm bias): Linear bias + W beta
+                assert f.derive[0] == "bias_fold" and not f.f16
+                seen.append(f.derive[2])
+            if f.fold:                       # norm weight folded into this projection's columns
                 seen.append(f.fold)
                 assert f.tiled and canon[f.fold] == (f.shape[1],)
             if f.tiled:
