@@ -78,7 +78,7 @@ struct opus_ctx {
     float *e_x, *e_hid, *p_pool_dummy, *e_part, *e_stat;
     half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
     half_t *p_xn, *p_y, *p_z[2];
-    float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws, *d_probs, *d_zpart, *d_spart;
+    float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws, *d_probs, *d_zpart, *d_spart, *d_part, *d_stat;
     int32_t *d_cand_i, *d_cand_n;
     uint64_t *d_seed;
     int32_t *d_chosen;
@@ -111,9 +111,10 @@ struct opus_ctx {
     int rq_a_tiled = 0, rq_xh_tiled = 0, rq_c_tiled = 0;
     // one-shot requests, fused LayerNorm around gemm_pp_kernel (GemmParams::ln_*): producer (fp16(x) into e_xn + partials into
     // e_part; rq_ln_done reports back) and consumer (rows scaled / shifted with e_stat and this column-sum vector)
-    bool rq_ln_produce = false;
+    float *rq_ln_part = nullptr;         // producer: partials here, fp16(x) into rq_ln_xh
+    half_t *rq_ln_xh = nullptr;
     int rq_ln_done = 0;
-    const float *rq_ln_colsum = nullptr;
+    const float *rq_ln_stat = nullptr, *rq_ln_colsum = nullptr;   // consumer
     bool xln_tiled = false;              // d_xln currently holds fp16(x) in fragment order
     const float *xh_src = nullptr;       // fp32 buffer whose fp16 copy + sum-of-squares partials are valid
     bool use_row_scale = false;          // one-shot: the next gemm() multiplies its rows by the rstd from d_ssq
@@ -177,6 +178,8 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_qkv = k.take<half_t>(Md * QKV);
     c->d_ctx = k.take<half_t>(Md * QD);
     c->d_act = k.take<half_t>(Md * g.dec_ffn);
+    c->d_part = k.take<float>(Md * (H / 64 + 1) * 2);               // prefill RMSNorm fused around the big GEMM: partials, (0, rstd)
+    c->d_stat = k.take<float>(Md * 2);
     c->d_xl = k.take<float>(B * H);
     c->d_xln = k.take<half_t>(B16 * H);
     c->d_logits = k.take<float>(B * (size_t)g.dec_vocab);
@@ -484,8 +487,8 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     p.force_wide = c->rq_force_wide; p.slab_only = c->rq_slab_only; p.ks_out = &c->rq_ks;
     c->rq_force_wide = c->rq_slab_only = 0;
     c->rq_ln_done = 0;
-    if (c->rq_ln_produce) { p.xh_out = c->e_xn; p.ssq_out = nullptr; p.ln_part = c->e_part; p.ln_done = &c->rq_ln_done; c->rq_ln_produce = false; }
-    if (c->rq_ln_colsum) { p.ln_stat = c->e_stat; p.ln_colsum = c->rq_ln_colsum; c->rq_ln_colsum = nullptr; }
+    if (c->rq_ln_part) { p.xh_out = c->rq_ln_xh; p.ssq_out = nullptr; p.ln_part = c->rq_ln_part; p.ln_done = &c->rq_ln_done; c->rq_ln_part = nullptr; }
+    if (c->rq_ln_stat) { p.ln_stat = c->rq_ln_stat; p.ln_colsum = c->rq_ln_colsum; c->rq_ln_stat = c->rq_ln_colsum = nullptr; }
     p.a_tiled = c->rq_a_tiled; p.xh_tiled = c->rq_xh_tiled; p.c_tiled = c->rq_c_tiled;
     c->rq_a_tiled = c->rq_xh_tiled = c->rq_c_tiled = 0;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;
@@ -602,12 +605,12 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
     const bool fc1_pp = !no_ln_fusion && (D & 255) == 0 && gemm_goes_pp(M, F);
     bool have_stat = false;                        // e_xn = fp16(x), e_stat = (mu, rstd) of the current residual stream
     auto finalize = [&]() -> int {
-        KL(KC_NORM, 8.0 * M * (D / 64) + 8.0 * M, launch_ln_finalize(c->e_part, M, D / 64, D, g.enc_ln_eps, c->e_stat, s));
+        KL(KC_NORM, 8.0 * M * (D / 64) + 8.0 * M, launch_ln_finalize(c->e_part, M, D / 64, D, g.enc_ln_eps, 0, c->e_stat, s));
         return OPUS_OK;
     };
     for (int l = 0; l < g.enc_layers; ++l) {
         const EncLayer &L = c->enc[l];
-        if (have_stat && qkv_pp) c->rq_ln_colsum = L.sqkv;
+        if (have_stat && qkv_pp) { c->rq_ln_stat = c->e_stat; c->rq_ln_colsum = L.sqkv; }
         else KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, nullptr, nullptr, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
         // q <- rotary(q * hd^-0.5), k <- rotary(k): in the projection's epilogue when the big tiled kernel takes it (head_dim 64),
         // else by the stand-alone kernel on the stored projection (same arithmetic)
@@ -626,13 +629,13 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
         a.kstart = nullptr; a.kend = d_lens;
         a.B = B; a.T = T; a.heads = nh; a.group = 1; a.head_dim = hd; a.causal = 0; a.scale = 1.0f;
         KLF(KC_ATTN_PREFILL, 8.0 * M * D, 4.0 * B * (double)T * T * D, launch_attn_prefill(a, s));
-        c->rq_ln_produce = fc1_pp;
+        if (fc1_pp) { c->rq_ln_part = c->e_part; c->rq_ln_xh = c->e_xn; }
         OPC(gemm(c, s, c->e_ctx, D, L.wo, M, D, D, L.bo, EPI_NONE, c->e_x, c->e_x, D, 1));
         have_stat = c->rq_ln_done != 0;
-        if (have_stat) { OPC(finalize()); c->rq_ln_colsum = L.s1; }
+        if (have_stat) { OPC(finalize()); c->rq_ln_stat = c->e_stat; c->rq_ln_colsum = L.s1; }
         else KL(KC_NORM, 6.0 * M * D, launch_layernorm(c->e_x, nullptr, nullptr, g.enc_ln_eps, M, D, c->e_xn, nullptr, s));
         OPC(gemm(c, s, c->e_xn, D, L.w1, M, F, D, L.b1, EPI_GELU, nullptr, c->e_h1, F, 0));
-        c->rq_ln_produce = qkv_pp && l + 1 < g.enc_layers;
+        if (qkv_pp && l + 1 < g.enc_layers) { c->rq_ln_part = c->e_part; c->rq_ln_xh = c->e_xn; }
         OPC(gemm(c, s, c->e_h1, F, L.w2, M, D, F, L.b2, EPI_NONE, c->e_x, c->e_x, D, 1));
         have_stat = c->rq_ln_done != 0;
         if (have_stat) OPC(finalize());
@@ -884,9 +887,24 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
     const int M = B * T;
     KL(KC_OTHER, 1.0 * M, launch_mask_to_kstart(mask, B, T, c->d_kstart, s));
     KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
+    // RMSNorm fused around the big tiled GEMM, as the encoder's LayerNorm (GemmParams::ln_* with mu = 0): the wo / down epilogue
+    // leaves fp16(x) + per-slab sums of squares, the consuming projection scales its rows by rstd in its epilogue
+    static const bool no_ln_fusion = getenv("OPUS_NO_LN_FUSION") != nullptr;   // A/B aid
+    const bool qkv_pp = !no_ln_fusion && (H & 255) == 0 && (QKV & 255) == 0 && gemm_goes_pp(M, QKV);
+    const bool gu_pp = !no_ln_fusion && (H & 255) == 0 && (F & 127) == 0 && gemm_goes_pp(M, 2 * F);
+    bool have_stat = false;
+    auto finalize = [&]() -> int {
+        KL(KC_NORM, 8.0 * M * (H / 64) + 8.0 * M, launch_ln_finalize(c->d_part, M, H / 64, H, g.dec_rms_eps, 1, c->d_stat, s));
+        return OPUS_OK;
+    };
     for (int l = 0; l < g.dec_layers; ++l) {
         const DecLayer &L = c->dec[l];
-        OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wqkv, M, QKV, H, EPI_NONE, c->d_qkv, QKV, 0, L.bqkv));
+        if (have_stat && qkv_pp) {
+            c->rq_ln_stat = c->d_stat;
+            OPC(gemm(c, s, c->d_xn, H, L.wqkv, M, QKV, H, L.bqkv, EPI_NONE, nullptr, c->d_qkv, QKV, 0));
+        } else {
+            OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wqkv, M, QKV, H, EPI_NONE, c->d_qkv, QKV, 0, L.bqkv));
+        }
         KL(KC_OTHER, 4.0 * M * QKV,
            launch_dec_rope_cache(c->d_qkv, c->cs_dec, c->d_kstart, B, T, nh, nkv, hd, c->kc + l * c->cache_sl,
                                  c->vc + l * c->cache_sl, c->cache_sb, c->cache_sh, s));
@@ -899,11 +917,22 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
         a.B = B; a.T = T; a.heads = nh; a.group = nh / nkv; a.head_dim = hd; a.causal = 1;
         a.scale = 1.0f / sqrtf((float)hd);
         KLF(KC_ATTN_PREFILL, 2.0 * M * (QKV + QD), 2.0 * B * (double)T * T * QD, launch_attn_prefill(a, s));
-        if (fuse_rows() && M <= 96) c->rq_xh = c->d_xn;      // (d_ssq holds 128 rows)
+        if (gu_pp) { c->rq_ln_part = c->d_part; c->rq_ln_xh = c->d_xn; }
+        else if (fuse_rows() && M <= 96) c->rq_xh = c->d_xn;      // (d_ssq holds 128 rows)
         OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
         c->xh_src = c->rq_done ? c->d_x : nullptr;
-        OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wgu, M, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
+        have_stat = c->rq_ln_done != 0;
+        if (have_stat) {
+            OPC(finalize());
+            c->rq_ln_stat = c->d_stat;
+            OPC(gemm(c, s, c->d_xn, H, L.wgu, M, 2 * F, H, nullptr, EPI_SILU_GU16, nullptr, c->d_act, F, 0));
+        } else {
+            OPC(gemm_norm(c, s, c->d_x, g.dec_rms_eps, c->d_xn, L.wgu, M, 2 * F, H, EPI_SILU_GU16, c->d_act, F, 0));
+        }
+        if (qkv_pp && l + 1 < g.dec_layers) { c->rq_ln_part = c->d_part; c->rq_ln_xh = c->d_xn; }
         OPC(gemm(c, s, c->d_act, F, L.wd, M, H, F, nullptr, EPI_NONE, c->d_x, c->d_x, H, 1));
+        have_stat = c->rq_ln_done != 0;
+        if (have_stat) OPC(finalize());
     }
     KL(KC_OTHER, 8.0 * B * H, launch_take_last(c->d_x, B, T, H, c->d_xl, s));
     OPC(lm_head(c, s, B));

@@ -127,6 +127,7 @@ struct GemmParams {
     //   and, per row and 64-column slab, (sum x, sum x^2) to ln_part[(m * N/64 + slab) * 2]; sets *ln_done;
     //  consumer side (fp16 output, EPI_NONE / GELU): A is fp16(x) as it stands, ln_stat[m] = (mu, rstd), ln_colsum = s,
     //   bias = c2; the epilogue applies the affine form above before the activation / the fused rotary.
+    //  RMSNorm (the decoder prefill) is the same with mu = 0: ln_colsum = nullptr, any epilogue incl. the gate / up pair.
     float *ln_part = nullptr;
     int *ln_done = nullptr;
     const float *ln_stat = nullptr;
@@ -205,7 +206,8 @@ hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s);
 hipError_t launch_layernorm(const float *x, const float *w, const float *b, float eps, int64_t rows, int D,
                             half_t *out_h, float *out_f, hipStream_t s);   // (w == b == nullptr: (x - mu) rstd, no affine part)
 // (mu, rstd) per row from the per-slab (sum x, sum x^2) partials the LayerNorm-producing GEMM epilogue left (GemmParams::ln_part)
-hipError_t launch_ln_finalize(const float *part, int64_t rows, int nslab, int D, float eps, float *stat, hipStream_t s);
+// (rms != 0: RMSNorm - (0, rsqrt(mean x^2 + eps)))
+hipError_t launch_ln_finalize(const float *part, int64_t rows, int nslab, int D, float eps, int rms, float *stat, hipStream_t s);
 hipError_t launch_rmsnorm(const float *x, const float *w, float eps, int64_t rows, int D, half_t *out,
                           hipStream_t s);
 hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipStream_t s);

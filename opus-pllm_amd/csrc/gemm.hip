@@ -1201,9 +1201,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         m = m < p.M ? m : p.M - 1;
         st = reinterpret_cast<const float2 *>(p.ln_stat)[m];
     };
-    if constexpr (LNA) {
+    if constexpr (LNA && EPI != EPI_SILU_GU16) {
         cb[lane] = p.bias ? p.bias[n0 + wc * 64 + lane] : 0.f;
-        cb[64 + lane] = p.ln_colsum[n0 + wc * 64 + lane];
+        cb[64 + lane] = p.ln_colsum ? p.ln_colsum[n0 + wc * 64 + lane] : 0.f;   // (nullptr: RMSNorm, mu = 0)
+    }
+    if constexpr (LNA) {
         load_stat(0, lst[0][0]);
         load_stat(1, lst[0][1]);
     }
@@ -1248,108 +1250,130 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
             for (int q = 0; q < 4; ++q) rr[q] = src[q];
         }
     };
-    float4 rbuf[2][RB][NR];
+    // Stores go through buffer descriptors that cover exactly the rows of this tile that exist: a row >= M is dropped by the
+    // hardware's range check, with no branch.  (With `if (m < M) store` the stores sit in exec-masked blocks; the compiler then
+    // cannot count them and every wait for the NEXT pair's prefetched residual / rotary / LayerNorm rows became a drain of all
+    // outstanding stores - 4 to 8 us per tile.)  For the same reason the whole loop is instantiated per epilogue mode - what
+    // is loaded and stored is fixed at compile time inside each instance - and the mode is chosen once, outside.
+    const int rows_left = p.M - m0 < 256 ? p.M - m0 : 256;
+    const int esz = p.out_f32 ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(p.C) + (int64_t)m0 * p.ldc * esz, 0, (int)((int64_t)rows_left * p.ldc * esz), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.ln_part ? reinterpret_cast<char *>(p.xh_out) + (int64_t)m0 * p.N * 2 : nullptr, 0, p.ln_part ? (int)((int64_t)rows_left * p.N * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        p.ln_part ? reinterpret_cast<char *>(p.ln_part) + (int64_t)m0 * (p.N >> 6) * 8 : nullptr, 0, p.ln_part ? (int)((int64_t)rows_left * (p.N >> 6) * 8) : 0, 0x00020000);
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    enum { M_F16 = 0, M_F32RES = 1, M_F32RES_LN = 2, M_ROPE = 3, M_GENERIC = 4 };
+    auto run = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool RES = MODE == M_F32RES || MODE == M_F32RES_LN;          // fp32 output + fp32 residual
+        constexpr bool CS = MODE == M_ROPE;
+        float4 rbuf[2][RB][NR];
+        if constexpr (RES || CS || MODE == M_GENERIC) {
 #pragma unroll
-    for (int q = 0; q < NR; ++q)
+            for (int q = 0; q < NR; ++q)
 #pragma unroll
-        for (int u = 0; u < RB; ++u) rbuf[0][u][q] = rbuf[1][u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.residual) {
-#pragma unroll
-        for (int u = 0; u < RB; ++u) load_res(u, rbuf[0][u]);
-    } else if (rope_on) {
-#pragma unroll
-        for (int u = 0; u < RB; ++u) load_cs(u, rbuf[0][u]);
-    }
-#pragma unroll
-    for (int ib = 0; ib < 8 / RB; ++ib) {
-        if (p.residual && ib + 1 < 8 / RB) {
-#pragma unroll
-            for (int u = 0; u < RB; ++u) load_res((ib + 1) * RB + u, rbuf[(ib + 1) & 1][u]);
-        } else if (rope_on && ib + 1 < 8 / RB) {
-#pragma unroll
-            for (int u = 0; u < RB; ++u) load_cs((ib + 1) * RB + u, rbuf[(ib + 1) & 1][u]);
+                for (int u = 0; u < RB; ++u) rbuf[0][u][q] = rbuf[1][u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if constexpr (LNA) {
-            if (ib + 1 < 8 / RB) {
-                load_stat((ib + 1) * RB, lst[(ib + 1) & 1][0]);
-                load_stat((ib + 1) * RB + 1, lst[(ib + 1) & 1][1]);
+        auto prefetch = [&](int ib2) {                                    // rows of the pair ib2 (unconditional inside a mode)
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                if constexpr (RES) load_res(ib2 * RB + u, rbuf[ib2 & 1][u]);
+                else if constexpr (CS) load_cs(ib2 * RB + u, rbuf[ib2 & 1][u]);
+                else if constexpr (MODE == M_GENERIC) { if (p.residual) load_res(ib2 * RB + u, rbuf[ib2 & 1][u]); }
             }
-        }
-        // 1. bias / activation in registers, 4 columns per lane -> patch image u, row li
+            if constexpr (LNA) {
+                load_stat(ib2 * RB, lst[ib2 & 1][0]);
+                load_stat(ib2 * RB + 1, lst[ib2 & 1][1]);
+            }
+        };
+        prefetch(0);
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int i = ib * RB + u;
-            float *pu = patch + u * PIMG;
-            if (EPI == EPI_SILU_GU16) {
+        for (int ib = 0; ib < 8 / RB; ++ib) {
+            if (ib + 1 < 8 / RB) prefetch(ib + 1);
+            // 1. bias / activation in registers, 4 columns per lane -> patch image u, row li
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    f4 v;
+            for (int u = 0; u < RB; ++u) {
+                const int i = ib * RB + u;
+                float *pu = patch + u * PIMG;
+                if (EPI == EPI_SILU_GU16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gate = acc[i][2 * jj][r] + bz[jj * 8 + r], up = acc[i][2 * jj + 1][r] + bz[jj * 8 + 4 + r];
-                        v[r] = silu(gate) * up;
+                    for (int jj = 0; jj < 2; ++jj) {
+                        f4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float gate = acc[i][2 * jj][r], up = acc[i][2 * jj + 1][r];
+                            if constexpr (LNA) {                     // RMSNorm row scale (no bias in the gate / up projections)
+                                gate *= lst[ib & 1][u].y;
+                                up *= lst[ib & 1][u].y;
+                            } else {
+                                gate += bz[jj * 8 + r];
+                                up += bz[jj * 8 + 4 + r];
+                            }
+                            v[r] = silu(gate) * up;
+                        }
+                        *reinterpret_cast<f4 *>(pu + pidx(li, jj * 16 + 4 * g)) = v;
                     }
-                    *reinterpret_cast<f4 *>(pu + pidx(li, jj * 16 + 4 * g)) = v;
-                }
-            } else {
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f4 v = acc[i][j];
-                    f4 b4 = f4{0.f, 0.f, 0.f, 0.f}, c4 = b4;
-                    if constexpr (LNA) {
-                        b4 = *reinterpret_cast<const f4 *>(cb + j * 16 + 4 * g);
-                        c4 = *reinterpret_cast<const f4 *>(cb + 64 + j * 16 + 4 * g);
-                    }
+                    for (int j = 0; j < 4; ++j) {
+                        f4 v = acc[i][j];
+                        f4 b4 = f4{0.f, 0.f, 0.f, 0.f}, c4 = b4;
+                        if constexpr (LNA) {
+                            b4 = *reinterpret_cast<const f4 *>(cb + j * 16 + 4 * g);
+                            c4 = *reinterpret_cast<const f4 *>(cb + 64 + j * 16 + 4 * g);
+                        }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if constexpr (LNA) v[r] = __builtin_fmaf(lst[ib & 1][u].y, v[r] - lst[ib & 1][u].x * c4[r], b4[r]);
-                        else v[r] += bz[j * 4 + r];
-                        if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (LNA) v[r] = __builtin_fmaf(lst[ib & 1][u].y, v[r] - lst[ib & 1][u].x * c4[r], b4[r]);
+                            else v[r] += bz[j * 4 + r];
+                            if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
+                        }
+                        *reinterpret_cast<f4 *>(pu + pidx(li, j * 16 + 4 * g)) = v;
                     }
-                    *reinterpret_cast<f4 *>(pu + pidx(li, j * 16 + 4 * g)) = v;
                 }
             }
-        }
-        // same-wave LDS round trip (in-order LDS queue); the fences keep the compiler from reordering across it
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // 2. row segments: lane -> (row, 4- or 8-column piece)
+            // same-wave LDS round trip (in-order LDS queue); the fences keep the compiler from reordering across it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // 2. row segments: lane -> (row, 4- or 8-column piece)
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int i = ib * RB + u;
-            const float *pu = patch + u * PIMG;
-            float4 (&rcur)[NR] = rbuf[ib & 1][u];
-            const int mrow0 = m0 + wr * 128 + i * 16;
-            if (p.out_f32) {
+            for (int u = 0; u < RB; ++u) {
+                const int i = ib * RB + u;
+                const float *pu = patch + u * PIMG;
+                float4 (&rcur)[NR] = rbuf[ib & 1][u];
+                const int tr0 = wr * 128 + i * 16;                          // first row of this row tile inside the 256-row tile
+                const bool f32_out = MODE == M_GENERIC ? p.out_f32 != 0 : RES;
+                if (f32_out) {
 #pragma unroll
-                for (int ps = 0; ps < 16 / RPP32; ++ps) {
-                    const int r = ps * RPP32 + lane / LPR32, c = (lane % LPR32) * 4;
-                    const int m = mrow0 + r;
-                    f4 v = *reinterpret_cast<const f4 *>(pu + pidx(r, c));
-                    if (m < p.M) {
-                        const float4 rr = rcur[ps];
-                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + nw0 + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    for (int ps = 0; ps < 16 / RPP32; ++ps) {
+                        const int r = ps * RPP32 + lane / LPR32, c = (lane % LPR32) * 4;
+                        f4 v = *reinterpret_cast<const f4 *>(pu + pidx(r, c));
+                        if constexpr (RES || MODE == M_GENERIC) {
+                            const float4 rr = rcur[ps];
+                            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), crs, ((tr0 + r) * (int)p.ldc + nw0 + c) * 4, 0, 0);
+                        if constexpr (MODE == M_F32RES_LN) {
+                            // fused LayerNorm / RMSNorm, producer side: fp16(x) + this slab's (sum x, sum x^2) of the row
+                            const h4 xh = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, xh), xrs, ((tr0 + r) * p.N + nw0 + c) * 2, 0, 0);
+                            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                            for (int o = 1; o < LPR32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                            const float2 st = make_float2(s1, s2);
+                            // (one lane per row writes; the others are sent out of range)
+                            const int poff = (lane % LPR32) == 0 ? ((tr0 + r) * (p.N >> 6) + (nw0 >> 6)) * 8 : 0x7ffffff0;
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, st), prs, poff, 0, 0);
+                        }
                     }
-                    if (p.ln_part) {   // fused LayerNorm, producer side (wave-uniform): fp16(x) + this slab's (sum x, sum x^2) of the row
-                        if (m < p.M)
-                            *reinterpret_cast<h4 *>(p.xh_out + (int64_t)m * p.N + nw0 + c) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-                        for (int o = 1; o < LPR32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                        if (m < p.M && (lane % LPR32) == 0)
-                            reinterpret_cast<float2 *>(p.ln_part)[(int64_t)m * (p.N >> 6) + (nw0 >> 6)] = make_float2(s1, s2);
-                    }
-                }
-            } else {
-                bool rotated = false;
-                if constexpr (ROPE_OK) {
-                    if (rope_on) {
-                        rotated = true;
+                } else if (CS || (MODE == M_GENERIC && rope_on)) {
+                    if constexpr (ROPE_OK) {
                         const int r = lane >> 2, c = (lane & 3) * 8;
-                        const int m = mrow0 + r;
                         const f4 l0 = *reinterpret_cast<const f4 *>(pu + pidx(r, c)), l1 = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 4));
                         const f4 h0 = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 32)), h1 = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 36));
                         const float qs = nw0 < p.rope_qcols ? p.rope_qscale : 1.0f;
@@ -1366,34 +1390,41 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                             olo[e] = (half_t)rl;
                             ohi[e] = (half_t)rh;
                         }
-                        if (m < p.M) {
-                            half_t *dst = reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c;
-                            *reinterpret_cast<h8 *>(dst) = olo;
-                            *reinterpret_cast<h8 *>(dst + 32) = ohi;
-                        }
+                        const int off = ((tr0 + r) * (int)p.ldc + nw0 + c) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, olo), crs, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, ohi), crs, off + 64, 0, 0);
                     }
-                }
-                if (!rotated) {
+                } else {
 #pragma unroll
                     for (int ps = 0; ps < 16 / RPP16; ++ps) {
                         const int r = ps * RPP16 + lane / LPR16, c = (lane % LPR16) * 8;
-                        const int m = mrow0 + r;
                         f4 lo = *reinterpret_cast<const f4 *>(pu + pidx(r, c)), hi = *reinterpret_cast<const f4 *>(pu + pidx(r, c + 4));
-                        if (m < p.M) {
-                            if constexpr (!LNA) {                    // (the LayerNorm consumer form has no residual)
-                                const float4 r0 = rcur[2 * ps], r1 = rcur[2 * ps + 1];
-                                lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
-                                hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
-                            }
-                            *reinterpret_cast<h8 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + nw0 + c) =
-                                h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+                        if constexpr (MODE == M_GENERIC) {                // (fp16 output with an fp32 residual: not on the path)
+                            const float4 r0 = rcur[2 * ps], r1 = rcur[2 * ps + 1];
+                            lo[0] += r0.x; lo[1] += r0.y; lo[2] += r0.z; lo[3] += r0.w;
+                            hi[0] += r1.x; hi[1] += r1.y; hi[2] += r1.z; hi[3] += r1.w;
                         }
+                        const h8 o = h8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o), crs, ((tr0 + r) * (int)p.ldc + nw0 + c) * 2, 0, 0);
                     }
                 }
             }
+            // the patch images are rewritten by the next pair of row tiles: the reads above must have retired (same wave, in order)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        // the patch images are rewritten by the next pair of row tiles: the reads above must have retired (same wave, in order)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if constexpr (LNA) {                                               // (the host side guarantees fp16 output, no residual)
+        if (rope_on) run(std::integral_constant<int, ROPE_OK ? M_ROPE : M_F16>{});
+        else run(std::integral_constant<int, M_F16>{});
+    } else if constexpr (EPI != EPI_NONE) {                            // GELU / gate-up epilogues: fp16 output on the path
+        if (!p.out_f32 && !p.residual) run(std::integral_constant<int, M_F16>{});
+        else run(std::integral_constant<int, M_GENERIC>{});
+    } else {
+        if (rope_on) run(std::integral_constant<int, M_ROPE>{});
+        else if (!p.out_f32 && !p.residual) run(std::integral_constant<int, M_F16>{});
+        else if (p.out_f32 && p.residual && p.ln_part) run(std::integral_constant<int, M_F32RES_LN>{});
+        else if (p.out_f32 && p.residual) run(std::integral_constant<int, M_F32RES>{});
+        else run(std::integral_constant<int, M_GENERIC>{});
     }
     if (p.trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1424,7 +1455,7 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
     constexpr int RW = 8;                                            // rows per wave
     // fused LayerNorm, consumer side (GemmParams::ln_stat): column sums of this lane's 4 columns, (mu, rstd) per row below
     f4 csum = f4{0.f, 0.f, 0.f, 0.f};
-    if (p.ln_stat) {
+    if (p.ln_stat && p.ln_colsum) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (n + c < p.N) csum[c] = p.ln_colsum[n + c];
@@ -1468,8 +1499,9 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
             f4 up;
 #pragma unroll
             for (int c = 0; c < 4; ++c) up[c] = __shfl_down(x[c], 4, 64);
+            const float rs = p.ln_stat ? reinterpret_cast<const float2 *>(p.ln_stat)[m < p.M ? m : p.M - 1].y : 1.0f;   // RMSNorm row scale
 #pragma unroll
-            for (int c = 0; c < 4; ++c) x[c] = silu(x[c] + bias4[c]) * (up[c] + bias_up[c]);
+            for (int c = 0; c < 4; ++c) x[c] = silu(x[c] * rs + bias4[c]) * (up[c] * rs + bias_up[c]);
             no = ((n >> 5) << 4) + (n & 15);
             live = live && gate_lane && n + 16 < p.N;
         } else {
@@ -1491,6 +1523,16 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
             }
             if (p.out_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + no) = make_float4(x[0], x[1], x[2], x[3]);
             else *reinterpret_cast<h4 *>(reinterpret_cast<half_t *>(p.C) + (int64_t)m * p.ldc + no) = h4{(half_t)x[0], (half_t)x[1], (half_t)x[2], (half_t)x[3]};
+            if (EPI == EPI_NONE && p.ln_part) {
+                // fused LayerNorm / RMSNorm, producer side, as gemm_pp_kernel's epilogue (N % 256 == 0: `live` is wave-uniform
+                // here, and 16 consecutive lanes hold one 64-column slab of the row)
+                *reinterpret_cast<h4 *>(p.xh_out + (int64_t)m * p.N + no) = h4{(half_t)x[0], (half_t)x[1], (half_t)x[2], (half_t)x[3]};
+                float s1 = (x[0] + x[1]) + (x[2] + x[3]);
+                float s2 = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if ((lane & 15) == 0) reinterpret_cast<float2 *>(p.ln_part)[(int64_t)m * (p.N >> 6) + (no >> 6)] = make_float2(s1, s2);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -1511,15 +1553,13 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
     // fused LayerNorm (GemmParams::ln_*): the consumer form must be honoured (the caller handed over un-normalised rows),
     // the producer form is best effort (*ln_done reports it)
     const bool lna = p.ln_stat != nullptr;
-    if (lna && (EPI == EPI_SILU_GU16 || !p.ln_colsum || p.out_f32 || p.residual || (p.N & 255) || (p.ldc & 7))) return hipErrorInvalidValue;
+    if (lna && (p.out_f32 || p.residual || (p.N & 255) || (p.ldc & 7) || (EPI == EPI_SILU_GU16 && (p.bias || p.ln_colsum)))) return hipErrorInvalidValue;
     const bool lnp = p.ln_part && p.xh_out && p.ln_done && EPI == EPI_NONE && p.out_f32 && (p.N & 255) == 0 && (p.ldc & 7) == 0 &&
                      (p.ldr & 3) == 0 && p.residual;
     if (lnp) *p.ln_done = 1;
     else p.ln_part = nullptr;
     void (*kern)(GemmParams, int, int, int, int) = gemm_pp_kernel<EPI, false>;
-    if constexpr (EPI != EPI_SILU_GU16) {
-        if (lna) kern = gemm_pp_kernel<EPI, true>;
-    }
+    if (lna) kern = gemm_pp_kernel<EPI, true>;
     const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(kern), 8 * 16384);
     if (ea != hipSuccess) return ea;
@@ -1534,7 +1574,7 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
     if (rope) *p.rope_done = 1;
     else p.rope_cs = nullptr;
     const int R = T % 256;
-    if (!no_tail && !rope && !lnp && p.ws && T > 256 && R > 0 && R <= 128) {   // (rope / LayerNorm-producing epilogues run in gemm_pp_kernel only)
+    if (!no_tail && !rope && p.ws && T > 256 && R > 0 && R <= 128) {   // (the fused rotary runs in gemm_pp_kernel's epilogue only)
         int sp = 256 / R;
         sp = sp > 8 ? 8 : sp;
         if (sp > KT / 4) sp = KT / 4;                                 // at least 4 k-tiles per part (pipeline prologue)

@@ -100,29 +100,42 @@ hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipSt
 }
 
 // (mu, rstd) of every row from the per-64-column (sum x, sum x^2) partials of the LayerNorm-producing GEMM epilogue
-// (GemmParams::ln_part), summed in slab order.  var = E[x^2] - mu^2 in fp32 (clamped at 0): the residual streams this serves
+// (GemmParams::ln_part), summed in a fixed order.  var = E[x^2] - mu^2 in fp32 (clamped at 0): the residual streams this serves
 // have |mu| of the order of the standard deviation or below, where the cancellation costs a few ulps of the variance.
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2 *__restrict__ part, int64_t rows, int nslab, float inv_d,
-                                                          float eps, float2 *__restrict__ stat) {
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= rows) return;
+                                                          float eps, int rms, float2 *__restrict__ stat) {
+    // 16 lanes per row: lane q takes slabs q, q + 16, ... (all requested at once), then a fixed-order 16-lane tree
+    const int q = threadIdx.x & 15;
+    int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = m < rows;
+    m = live ? m : rows - 1;
     const float2 *src = part + m * nslab;
     float s1 = 0.f, s2 = 0.f;
-    for (int j0 = 0; j0 < nslab; j0 += 8) {                          // 8 partials requested at a time, added in slab order
-        float2 t[8];
+    for (int j0 = 0; j0 < nslab; j0 += 64) {
+        float2 t[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = src[j0 + u < nslab ? j0 + u : nslab - 1];
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 16 * u + q;
+            t[u] = src[j < nslab ? j : nslab - 1];
+            if (j >= nslab) t[u] = make_float2(0.f, 0.f);
+        }
+        s1 += (t[0].x + t[1].x) + (t[2].x + t[3].x);
+        s2 += (t[0].y + t[1].y) + (t[2].y + t[3].y);
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (j0 + u < nslab) { s1 += t[u].x; s2 += t[u].y; }
+    for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (!live || q) return;
+    if (rms) {                                                        // RMSNorm: (0, rsqrt(mean x^2 + eps))
+        stat[m] = make_float2(0.f, rsqrtf(s2 * inv_d + eps));
+        return;
     }
     const float mu = s1 * inv_d;
     const float var = fmaxf(s2 * inv_d - mu * mu, 0.f);
     stat[m] = make_float2(mu, rsqrtf(var + eps));
 }
-hipError_t launch_ln_finalize(const float *part, int64_t rows, int nslab, int D, float eps, float *stat, hipStream_t s) {
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(part), rows, nslab,
-                       1.0f / (float)D, eps, reinterpret_cast<float2 *>(stat));
+hipError_t launch_ln_finalize(const float *part, int64_t rows, int nslab, int D, float eps, int rms, float *stat, hipStream_t s) {
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(rows, 16)), dim3(256), 0, s, reinterpret_cast<const float2 *>(part), rows, nslab,
+                       1.0f / (float)D, eps, rms, reinterpret_cast<float2 *>(stat));
     return hipGetLastError();
 }
 
