@@ -1,7 +1,7 @@
 // Flash-style attention for the encoder (bidirectional, key-padding) and the decoder prefill (causal, left-padded rows,
 // GQA).  O(T) memory: the reference stack materialises the [h,T,T] scores.
 //
-// Workgroup = 4 waves = 128 query rows (32 per wave: two 16-query tiles) of one (batch, head); K/V tiles of 64 keys are
+// Workgroup = 4 waves = 64 QT query rows (QT 16-query tiles per wave) of one (batch, head); K/V tiles of 64 keys are
 // double-buffered in LDS (global -> registers one tile ahead, written after the tile's compute: one barrier per tile).
 // The products are "swapped" so that a QUERY lives on a lane and the softmax never crosses lanes inside a tile:
 //   S^T = K Q^T      MFMA 16x16x32 f16 : A = 16 keys x 32 dims (LDS, XOR-swizzled rows), B = Q^T (registers).  The result
@@ -19,8 +19,6 @@
 
 namespace opus {
 
-constexpr int QW = 32;          // queries per wave
-constexpr int QB = 4 * QW;      // queries per workgroup
 constexpr int KB = 64;          // keys per tile
 
 template <int HDP>
@@ -42,8 +40,11 @@ __device__ __forceinline__ int vswz(int row) {
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
 
-template <int HD, bool CAUSAL>
+// QT = 16-query tiles per wave (queries per wave QW = 16 QT, per workgroup QB = 64 QT).  Two tiles share every K / V fragment
+// read; one tile halves the registers (two more waves per SIMD at head_dim 64) and the ragged last query block.
+template <int HD, bool CAUSAL, int QT>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
+    constexpr int QW = 16 * QT, QB = 4 * QW;
     constexpr int HDP = HD < 32 ? 32 : HD;      // QK^T k extent (zero-padded for head_dim 16)
     constexpr int KS = HDP / 32;                // MFMA k-steps for QK^T
     constexpr int NO = HD / 16;                 // output dim tiles
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     const half_t *Vb = p.V + (int64_t)b * p.v_sb + (int64_t)hk * HD;
 
     // Q^T fragments (B operand): column li = query, k = 32 s + 8 g + e
-    h8 qf[2][KS];
+    h8 qf[QT][KS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < QT; ++t) {
         int qr = qw + 16 * t + li;
         qr = qr < p.T ? qr : p.T - 1;
         const half_t *src = Qb + (int64_t)qr * p.q_st;
@@ -84,10 +85,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
             qf[t][s] = d < HD ? *reinterpret_cast<const h8 *>(src + d) : h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    f4 o[2][NO];
-    float mrow[2], lrow[2];
+    f4 o[QT][NO];
+    float mrow[QT], lrow[QT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < QT; ++t) {
         mrow[t] = -INFINITY;
         lrow[t] = 0.f;
 #pragma unroll
@@ -148,18 +149,21 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     __syncthreads();
     int buf = 0;
     for (int kt = k_lo; kt < k_hi; kt += KB, buf ^= 1) {
-        if (wave_live) {
+        // the tile's compute for the first NSUB 16-key subtiles (4 = the whole tile; fewer for a short last tile: T = 514 ends
+        // with a tile of 2 keys, which costs a quarter of a full one this way)
+        auto tile_body = [&](auto nsub_tag) {
+            constexpr int NSUB = decltype(nsub_tag)::value, NJ = (NSUB + 1) / 2;
             const half_t *tK = sK[buf], *tV = sV[buf];
-            // ---- S^T = K Q^T : 4 key subtiles x 2 query tiles ----
-            f4 s[2][4];
+            // ---- S^T = K Q^T : NSUB key subtiles x QT query tiles ----
+            f4 s[QT][4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NSUB; ++n) {
                 const int r = 16 * n + li;
                 h8 kf[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const h8 *>(tK + r * HDP + kswz<HDP>(r, 4 * ks + g) * 8);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < QT; ++t) {
                     s[t][n] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) s[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[ks], qf[t][ks], s[t][n], 0, 0, 0);
@@ -168,15 +172,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
             // ---- mask + online softmax: lane (li, g) owns query qw + 16 t + li, keys kt + 16 n + 4 g + r ----
             // interior: every key of the tile is visible to every query row of this wave (wave-uniform): no masking code
             const bool interior = kt >= kstart && kt + KB <= kend && (!CAUSAL || kt + KB - 1 <= qw);
-            h8 pf[2][2];
+            h8 pf[QT][2];
             auto softmax = [&](auto masked_tag) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < QT; ++t) {
                     if (MASKED) {                                        // tiles that touch a padding / causal boundary
                         const int qi = qw + 16 * t + li;
 #pragma unroll
-                        for (int n = 0; n < 4; ++n)
+                        for (int n = 0; n < NSUB; ++n)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int kj = kt + 16 * n + 4 * g + r;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                     // row maximum of the raw scores (the scale is positive): 16 in-lane values, then the four lane groups
                     float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
 #pragma unroll
-                    for (int n = 1; n < 4; ++n) mx = fmaxf(fmaxf(mx, fmaxf(s[t][n][0], s[t][n][1])), fmaxf(s[t][n][2], s[t][n][3]));
+                    for (int n = 1; n < NSUB; ++n) mx = fmaxf(fmaxf(mx, fmaxf(s[t][n][0], s[t][n][1])), fmaxf(s[t][n][2], s[t][n][3]));
                     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                     const float mnew = fmaxf(mrow[t], mx);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                     }
                     float rs = 0.f;
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
+                    for (int n = 0; n < NSUB; ++n)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][n][r], sc, -msc));
@@ -213,9 +217,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                     lrow[t] += rs;                                       // this lane's keys only: summed over g at the end
                     // P^T fragments: 32-key step j = subtiles 2j, 2j+1; element e -> key 16 (2j + e/4) + 4g + e%4
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j) {
+                        const bool two = 2 * j + 1 < NSUB;               // (odd NSUB: the second subtile of the last step is absent)
                         pf[t][j] = h8{(half_t)s[t][2 * j][0], (half_t)s[t][2 * j][1], (half_t)s[t][2 * j][2], (half_t)s[t][2 * j][3],
-                                      (half_t)s[t][2 * j + 1][0], (half_t)s[t][2 * j + 1][1], (half_t)s[t][2 * j + 1][2], (half_t)s[t][2 * j + 1][3]};
+                                      two ? (half_t)s[t][two ? 2 * j + 1 : 0][0] : (half_t)0.f, two ? (half_t)s[t][two ? 2 * j + 1 : 0][1] : (half_t)0.f,
+                                      two ? (half_t)s[t][two ? 2 * j + 1 : 0][2] : (half_t)0.f, two ? (half_t)s[t][two ? 2 * j + 1 : 0][3] : (half_t)0.f};
+                    }
                 }
             };
             if (__builtin_expect(interior, 1)) softmax(std::false_type{});
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 #pragma unroll
             for (int n = 0; n < NO; ++n)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int r0 = 16 * (2 * j) + 4 * g + (li >> 2), r1 = r0 + 16;
                     const int cc = 2 * n + ((li & 3) >> 1), off = (li & 1) * 4;
                     const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -236,8 +243,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                     const s8v both = s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     const h8 vf = __builtin_bit_cast(h8, both);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][j], o[t][n], 0, 0, 0);
+                    for (int t = 0; t < QT; ++t) o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][j], o[t][n], 0, 0, 0);
                 }
+        };
+        if (wave_live) {
+            const int rem = k_hi - kt;                                   // keys of this tile below k_hi (wave-uniform)
+            if (rem > 32) tile_body(std::integral_constant<int, 4>{});
+            else if (rem > 16) tile_body(std::integral_constant<int, 2>{});
+            else tile_body(std::integral_constant<int, 1>{});
         }
         // next tile: registers -> the other LDS buffer (its last readers passed the previous barrier), then fetch the one after
         if (kt + KB < k_hi) {
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     // ---- epilogue: O / l -> fp16 [b, t, h*HD + d]; lane (li, g) holds dims 16 n + 4 g + r of query li ----
     if (!wave_live) return;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < QT; ++t) {
         float l = lrow[t];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -265,13 +278,24 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     }
 }
 
+template <int HD, int QT>
+static hipError_t launch_qt(const AttnParams &p, hipStream_t s) {
+    const int nqb = cdiv(p.T, 64 * QT);
+    dim3 grid(((p.B * p.heads + 7) / 8) * 8 * nqb);
+    if (p.causal) OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, true, QT>), grid, dim3(256), 0, s, p);
+    else OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, false, QT>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
 template <int HD>
 static hipError_t launch_hd(const AttnParams &p, hipStream_t s) {
-    const int nqb = cdiv(p.T, QB);
-    dim3 grid(((p.B * p.heads + 7) / 8) * 8 * nqb);
-    if (p.causal) OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, true>), grid, dim3(256), 0, s, p);
-    else OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, false>), grid, dim3(256), 0, s, p);
-    return hipGetLastError();
+    // Measured (tools/bench_attn.py ab, one MI355X, both forms in one process): one query tile per wave wins everywhere - it
+    // halves the registers (4 instead of 2 waves per SIMD at head_dim 64, 2 instead of 1 at 128), which matters more to this
+    // latency-bound loop than sharing the K / V fragment reads between two tiles: 64 x 514 x 20 heads x 64: 209-215 vs 267-272 us;
+    // 32 x 1026 x 40 x 64: 729 vs 737 us; batch-64 decoder prefill (96 positions, head_dim 128, causal): 50 vs 75 us; batch 1:
+    // 11 vs 18 us and 6 vs 10 us.  The two-tile form stays instantiated for A/B (knob misc3).
+    bool one = true;
+    if (g_knobs.misc[3]) one = !one;                                 // A/B aid
+    return one ? launch_qt<HD, 1>(p, s) : launch_qt<HD, 2>(p, s);
 }
 
 hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s) {

@@ -38,6 +38,17 @@ def bench(name, B, T, heads, group, hd, causal, iters=20):
     print(f"{name:28s} B={B:3d} T={T:5d} heads={heads:3d} hd={hd:3d} causal={causal}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 
+for flip in ((0, 1) if "ab" in sys.argv else (0,)):     # knob misc3 = 1 flips the query tiles per wave (1 <-> 2) of every head_dim
+    _cabi.check(lib.opus_debug_knob(model._ctx, b"misc3", flip))
+    print(f"== misc3 = {flip}: " + ("default choice of query tiles per wave" if not flip else "the other choice (1 <-> 2 tiles)"))
+    bench("esm650m B=64", 64, 514, 20, 1, 64, 0)
+    bench("esm650m B=64 T=512", 64, 512, 20, 1, 64, 0)
+    bench("esm650m B=1", 1, 514, 20, 1, 64, 0)
+    bench("esm3b B=32 L=1024", 32, 1026, 40, 1, 64, 0)
+    bench("llama prefill B=64", 64, 96, 32, 4, 128, 1)
+    bench("llama prefill B=1", 1, 96, 32, 4, 128, 1)
+_cabi.check(lib.opus_debug_knob(model._ctx, b"misc3", 0))
+sys.exit(0)
 bench("esm650m B=64", 64, 514, 20, 1, 64, 0)
 bench("esm650m B=1", 1, 514, 20, 1, 64, 0)
 bench("esm3b B=32 L=1024", 32, 1026, 40, 1, 64, 0)
