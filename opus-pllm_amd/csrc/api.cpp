@@ -87,7 +87,7 @@ struct opus_ctx {
     int64_t gemm_ws_bytes = 0;
     half_t *d_xn, *d_qkv, *d_ctx, *d_act, *d_xln, *kc, *vc;
     float *cs_enc, *cs_dec, *cs_row;
-    int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan, *d_pidx, *d_stop;
+    int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan, *d_pidx, *d_stop, *d_cnt;
     int n_stop = 0;                      // opt-in stop sequence (opus_set_stop_sequence)
     int64_t cache_sl, cache_sb, cache_sh;   // strides (halfs): layer, batch row, kv head
     // decode state
@@ -200,6 +200,7 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_nunf = k.take<int32_t>((size_t)g.max_new_tokens + 4);
     c->d_eos = k.take<int32_t>(64);
     c->d_stop = k.take<int32_t>(16);
+    c->d_cnt = k.take<int32_t>(1024);                               // ticket counters of gemm_stream_kernel's in-launch combine (zero between launches)
     c->d_plan = k.take<int32_t>(4 * B + 8);
     c->d_pval = k.take<float>(64 * B);
     c->d_probs = k.take<float>(B * ((size_t)g.dec_vocab + 64 * 4));     // candidate probabilities (per-part slots)
@@ -297,6 +298,7 @@ extern "C" int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **ou
         for (size_t i = 0; i < t.size(); i += 2) { t[i] = 1.0f; t[i + 1] = 0.0f; }
     HIPC(hipMemcpy(c->cs_dec, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPC(hipMemset(c->d_step, 0, 16));
+    HIPC(hipMemset(c->d_cnt, 0, 1024 * sizeof(int32_t)));
     // the decode attention reads whole 32-slot tiles and masks afterwards: every cache slot must hold finite values
     HIPC(hipMemset(c->kc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
     HIPC(hipMemset(c->vc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
@@ -489,6 +491,7 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     c->rq_ln_done = 0;
     if (c->rq_ln_part) { p.xh_out = c->rq_ln_xh; p.ssq_out = nullptr; p.ln_part = c->rq_ln_part; p.ln_done = &c->rq_ln_done; c->rq_ln_part = nullptr; }
     if (c->rq_ln_stat) { p.ln_stat = c->rq_ln_stat; p.ln_colsum = c->rq_ln_colsum; c->rq_ln_stat = c->rq_ln_colsum = nullptr; }
+    p.combine_cnt = c->d_cnt;
     p.a_tiled = c->rq_a_tiled; p.xh_tiled = c->rq_xh_tiled; p.c_tiled = c->rq_c_tiled;
     c->rq_a_tiled = c->rq_xh_tiled = c->rq_c_tiled = 0;
     const int nout = epi == EPI_SILU_GU16 ? N / 2 : N;

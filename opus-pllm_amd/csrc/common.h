@@ -120,6 +120,9 @@ struct GemmParams {
     // element (row, k) of an [rows, K] matrix at tiled_off(row, k, K).  a_tiled: A is stored that way (gemm_stream_kernel only);
     // xh_tiled / c_tiled: write xh_out / the fp16 output C that way (for a consumer that will read it with a_tiled).
     int a_tiled = 0, xh_tiled = 0, c_tiled = 0;
+    // gemm_stream_kernel with k-parts and a finished output: ticket counters (one int per column group, all zero between
+    // launches) of the in-launch combine; nullptr: slabs + a split-K reduce launch
+    int *combine_cnt = nullptr;
     // LayerNorm fused around the big tiled GEMM (gemm_pp_kernel; the encoder's pre-LN blocks).  With the norm
     // weight folded into the consumer's weight W' = W diag(gamma) and beta into its bias c2 = W beta + b,
     //   LN(x) W^T + b  =  rstd (x W'^T - mu s) + c2,   s[n] = sum_k W'[n][k]:

@@ -148,19 +148,13 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
         for (int i = 0; i < MT; ++i) red[(wave * TILES + j * MT + i) * 64 + lane] = acc[j][i];
     __syncthreads();
     const int npanels = p.N >> 4;
-    for (int tile = wave; tile < TILES; tile += NW) {    // wave-uniform
+    // the GEMM epilogue on the finished sums of one tile: this lane holds columns n .. n + 3 of row m
+    auto finish = [&](int tile, f4 v) {
         const int j = tile / MT, i = tile - j * MT;
-        f4 v = red[tile * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) v += red[(w * TILES + tile) * 64 + lane];
         const int m = 16 * i + li;
         const int panel = panel0 + j;
-        const int n = panel * 16 + 4 * g;                // this lane: columns n .. n + 3 of row m
+        const int n = panel * 16 + 4 * g;
         const bool live = m < p.M;
-        if (ksplit > 1) {                                // raw k-part slab, no epilogue
-            if (live) *reinterpret_cast<float4 *>(p.ws + ((int64_t)ky * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            continue;
-        }
         if (p.bias) {
             const float4 bz = *reinterpret_cast<const float4 *>(p.bias + n);
             v[0] += bz.x; v[1] += bz.y; v[2] += bz.z; v[3] += bz.w;
@@ -184,6 +178,53 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
             q += __shfl_xor(q, 32, 64);
             if (live && g == 0) p.ssq_out[(int64_t)m * npanels + panel] = q;
         }
+    };
+    typedef unsigned int u4s __attribute__((ext_vector_type(4)));
+    // k-part slabs through a descriptor: written through to memory (sc1) when another workgroup of this launch will read them
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.ws, 0, ksplit > 1 ? (int)((int64_t)ksplit * p.M * p.N * 4) : 0, 0x00020000);
+    const bool combine = ksplit > 1 && p.combine_cnt != nullptr;      // (kernel argument: uniform)
+    for (int tile = wave; tile < TILES; tile += NW) {    // wave-uniform
+        f4 v = red[tile * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[(w * TILES + tile) * 64 + lane];
+        if (ksplit == 1) { finish(tile, v); continue; }
+        const int j = tile / MT, i = tile - j * MT;
+        const int m = 16 * i + li, n = (panel0 + j) * 16 + 4 * g;
+        const int off = m < p.M ? (int)((((int64_t)ky * p.M + m) * p.N + n) * 4) : 0x7ffffff0;   // (rows >= M: dropped by the range check)
+        if (combine) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, v), wrs, off, 0, 16);   // aux 16 = sc1
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, v), wrs, off, 0, 0);
+    }
+    if (!combine) return;
+    // ---- in-launch combine of the k-parts (cdna_hip_programming.md "In-launch split-K reduction", sc1 form) ----
+    // every wave has drained its write-through slab stores; one lane draws a ticket; the workgroup that draws the last one
+    // reads all slabs of its column group with sc1 loads (L1 bypassed), sums them in k-part order - the same sums whichever
+    // workgroup arrives last - and runs the epilogue; it also re-arms the counter for the next launch.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *flag = reinterpret_cast<int *>(smem + (size_t)NW * TILES * 1024);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(p.combine_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != ksplit - 1) return;                     // uniform
+    if (tid == 0) __hip_atomic_store(p.combine_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int tile = wave; tile < TILES; tile += NW) {
+        const int j = tile / MT, i = tile - j * MT;
+        int m = 16 * i + li;
+        m = m < p.M ? m : p.M - 1;
+        const int n = (panel0 + j) * 16 + 4 * g;
+        u4s t[4];
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < ksplit; k0 += 4) {         // 4 slabs requested at a time, added in k-part order
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k0 + u < ksplit ? k0 + u : ksplit - 1;
+                t[u] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)((((int64_t)kk * p.M + m) * p.N + n) * 4), 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < ksplit) v += __builtin_bit_cast(f4, t[u]);
+        }
+        finish(tile, v);
     }
 }
 
@@ -243,12 +284,18 @@ template <int MT, int P, int NT, int U, int EPI>
 static hipError_t launch_stream_t(const GemmParams &p_in, const StreamPlan &pl, hipStream_t s) {
     GemmParams p = p_in;
     constexpr int NW = NT / 64;
-    const size_t lds = (size_t)NW * P * MT * 1024;
+    const size_t lds = (size_t)NW * P * MT * 1024 + 16;      // partial tiles + the "last arriver" word of the in-launch combine
     hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&gemm_stream_kernel<MT, P, NT, U, EPI>), lds);
     if (ea != hipSuccess) return ea;
     const int npanels = p.N >> 4;
-    // producer side of the row-scale fusion: fp32 output of the plain epilogue, room for M x N/16 partial sums
-    const bool fuse = pl.ks == 1 && EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 &&
+    // k-parts with a finished output: combined inside the launch by the workgroup that arrives last (no reduce launch)
+    static const bool no_combine = getenv("OPUS_NO_COMBINE") != nullptr;   // A/B aid: slabs + splitk_reduce instead
+    const bool combine = pl.ks > 1 && !p.slab_only && p.combine_cnt && !p.row_ssq && !no_combine && !g_knobs.misc[4];
+    if (!combine) p.combine_cnt = nullptr;
+    // producer side of the row-scale fusion (this kernel's own epilogue: one k-part, or the in-launch combine): fp32 output
+    // of the plain epilogue, room for M x N/16 partial sums.  With a split-K reduce behind the launch, the reduce does it.
+    const bool own_epilogue = pl.ks == 1 || combine;
+    const bool fuse = own_epilogue && EPI == EPI_NONE && p.xh_out && p.ssq_out && p.fused_done && p.out_f32 &&
                       (int64_t)p.M * npanels <= p.ssq_cap;
     if (fuse) { *p.fused_done = 1; if (p.nblk_out) *p.nblk_out = npanels; }
     else p.xh_out = nullptr;
@@ -256,7 +303,7 @@ static hipError_t launch_stream_t(const GemmParams &p_in, const StreamPlan &pl, 
     if (p.ks_out) *p.ks_out = pl.ks;
     OPUS_LAUNCH(KC_STREAM, (gemm_stream_kernel<MT, P, NT, U, EPI>), dim3(npanels / P, pl.ks), dim3(NT), lds, s, p, pl.ks);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || pl.ks == 1 || p_in.slab_only) return e;
+    if (e != hipSuccess || pl.ks == 1 || p_in.slab_only || combine) return e;
     return launch_splitk_reduce(p_in, pl.ks, s);                      // (applies bias / residual / row scale, writes xh_out + sums of squares)
 }
 

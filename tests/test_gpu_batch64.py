@@ -425,6 +425,9 @@ def test_stream_gemm_vs_fp64(big64, M, N, K, tiled):
         assert bool(torch.isfinite(out).all())
         err = (out.double().cpu() - ref).abs().max().item()
         assert err <= 2e-3 * ref.abs().max().item(), err
+        for _ in range(3):                                       # k-parts are combined by whichever workgroup arrives last:
+            again, _ = run(M, True, tiled)                       # the sums are taken in k-part order all the same
+            assert torch.equal(again, out)
         if 2 * 64 * K <= (600 if tiled else 280) * 1024:         # the same rows inside a 64-row launch: bit-identical
             full, n64 = run(64, True, tiled)
             assert n64 == 1 and torch.equal(full[:M], out)
