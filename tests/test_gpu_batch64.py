@@ -28,9 +28,9 @@ MARGIN_TAU = 0.05          # oracle / reference top-1 margin above which a greed
 # Bounds = about 3x what MI355X measured (DESIGN.md section 3 lists the observed values):
 ROW_VS_BATCH = 1e-3        # same math on different kernels, encoder / projector outputs (observed 1.2e-4 .. 2.3e-4)
 ROW_VS_BATCH_LOGITS = 3e-3 # ... and logits behind 32-40 decoder layers of fp16 hand-offs (observed 8.8e-4 .. 9.3e-4)
-ORACLE_POOLED = 1e-3       # fp16-operand HIP path vs the fp32 oracle: pooled embedding, 33 layers (observed 1.2e-4 .. 2.4e-4)
-ORACLE_PROT = 2e-3         # protein tokens (observed 4.4e-4 .. 5.0e-4)
-ORACLE_LOGITS = 3e-3       # logits, 32 layers (observed 7.0e-4 .. 8.9e-4)
+ORACLE_POOLED = 1e-3       # fp16-operand HIP path vs the fp32 oracle: pooled embedding, 33 layers (observed 2.4e-4 .. 3.1e-4)
+ORACLE_PROT = 2e-3         # protein tokens (observed 4.9e-4 .. 5.4e-4)
+ORACLE_LOGITS = 3e-3       # logits, 32 layers (observed 7.1e-4 .. 9.1e-4)
 
 
 def _model(cfg, dev):
@@ -101,7 +101,7 @@ def _row_vs_batch(model, cfg, seqs, ids, rows, tag):
     record(tag + ".row_vs_batch", dict(worst, decisive_steps=decisive, steps=checked))
     assert worst["pooled"] < ROW_VS_BATCH and worst["prot"] < ROW_VS_BATCH, worst
     assert worst["logits"] < ROW_VS_BATCH_LOGITS, worst
-    assert decisive >= checked // 2, (decisive, checked)        # the synthetic model is far from ties on most steps
+    assert decisive >= checked - 2, (decisive, checked)         # observed 15 / 16 / 16 of 16 (C4 / C3 / C5): far from ties
     return pooled, prot, emb, mask, steps, forced
 
 

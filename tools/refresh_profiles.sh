@@ -1,8 +1,10 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run through gpurun from the repo root):
 #   the bench line (default command: batch 64/GPU headline + configs[1] + projector stage), rocprofv3 kernel stats of the same
-#   command, PMC read / write passes (eager launches, one step: counters cannot be collected through hipGraph replays), the
-#   configs[2] (mixed lengths) and configs[4]-shape lines, and the two-stage pipeline demo under the kernel trace.
+#   command (+ per (kernel, grid) statistics of one step: the same kernel at its different shapes), PMC read / write passes of
+#   one batch-64 step and of one batch-1 step (eager launches: counters cannot be collected through hipGraph replays) set
+#   beside the algorithmic bytes of every kernel class, the configs[2] (mixed lengths) and configs[4]-shape lines, and the
+#   two-stage pipeline demo under the kernel trace.
 # Raw traces are summarised on the box and deleted (gpurun copies back at most 64 MiB).
 set -o pipefail
 TAG=${1:-r03}
@@ -10,12 +12,20 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 keep_stats() { find "$1" -name '*_kernel_stats.csv' -exec cp {} "$2" \; ; rm -rf "$1"; }
+pmc_pair() {   # $1 = tag, rest = bench.py arguments of the step
+  local t=$1; shift
+  OPUS_NO_GRAPH=1 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OUT/pmc_rd_$t -o rd --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline "$@" > $OUT/pmc_rd_$t.log 2>&1 &&
+  OPUS_NO_GRAPH=1 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_wr_$t -o wr --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline "$@" > $OUT/pmc_wr_$t.log 2>&1 &&
+  OPUS_NO_GRAPH=1 python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline "$@" > $OUT/bench_pmc_shape_$t.json 2> /dev/null &&
+  python3 tools/pmc_summary.py $OUT/pmc_rd_$t $OUT/pmc_wr_$t $OUT/pmc_traffic_$t.json $OUT/bench_pmc_shape_$t.json > $OUT/pmc_traffic_$t.txt &&
+  rm -rf $OUT/pmc_rd_$t $OUT/pmc_wr_$t $OUT/pmc_rd_$t.log $OUT/pmc_wr_$t.log
+}
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log && tail -c 300 $OUT/bench.json &&
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o main --output-format csv -- python3 bench.py --no-cpu-baseline --no-roofline > $OUT/stats.log 2>&1 &&
 keep_stats $OUT/stats $OUT/kernel_stats.csv &&
-OPUS_NO_GRAPH=1 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OUT/pmc_rd -o rd --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline > $OUT/pmc_rd.log 2>&1 &&
-OPUS_NO_GRAPH=1 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_wr -o wr --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline --no-roofline > $OUT/pmc_wr.log 2>&1 &&
-OPUS_NO_GRAPH=1 python3 bench.py --steps 1 --warmup 0 --no-c2 --no-cpu-baseline > $OUT/bench_pmc_shape.json 2> /dev/null && python3 tools/pmc_summary.py $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_traffic.json $OUT/bench_pmc_shape.json > $OUT/pmc_traffic.txt && rm -rf $OUT/pmc_rd $OUT/pmc_wr &&
+rocprofv3 --kernel-trace -d $OUT/shapes -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-c2 > $OUT/shapes.log 2>&1 &&
+python3 tools/prof_shapes.py $OUT/shapes 0.5 > $OUT/kernel_shapes.txt && rm -rf $OUT/shapes &&
+pmc_pair b64 && pmc_pair b1 --batch 1 &&
 python3 bench.py --mixed-lengths --steps 5 --warmup 2 --no-cpu-baseline --no-c2 > $OUT/bench_c3.json 2> $OUT/bench_c3.log &&
 python3 bench.py --model vicuna_13b --batch 32 --residues 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-c2 > $OUT/bench_c5.json 2> $OUT/bench_c5.log &&
 rocprofv3 --kernel-trace --stats -d $OUT/stats_two_stage -o ts --output-format csv -- python3 tools/two_stage_demo.py --n 4096 > $OUT/two_stage.log 2>&1 &&
