@@ -135,6 +135,8 @@ struct GemmParams {
     int *ln_done = nullptr;
     const float *ln_stat = nullptr;
     const float *ln_colsum = nullptr;
+    int pp_gm = 8;                // gemm_pp_kernel: tile rows per rasterisation group (8 = an 8 x 4 tile patch per XCD)
+    int stagger = 0;              // gemm_pp_kernel: late start of half of the first round, in units of ~4 us (see the kernel)
     int no_rot = 0;               // A/B aid (OPUS_NO_KROT): weight-streaming kernels walk k from chunk 0 in every workgroup
     long long *trace = nullptr;   // tuning aid (OPUS_PP_TRACE): gemm_pp_kernel writes 4 wall-clock stamps per workgroup
 };

@@ -946,8 +946,7 @@ constexpr int PP_DIST = 6;   // half-tiles requested ahead (4..6)
 
 // tile id -> (tile row, tile column): GM tile-rows are walked column by column, so the ~32 tiles an XCD works on at one time
 // form a compact 2-D patch sharing A rows and weight panels in that XCD's L2
-__host__ __device__ __forceinline__ void pp_tile_coords(int id, int tiles_m, int tiles_n, int &tm, int &tn) {
-    constexpr int GM = 8;
+__host__ __device__ __forceinline__ void pp_tile_coords(int id, int tiles_m, int tiles_n, int &tm, int &tn, int GM = 8) {
     const int per_group = GM * tiles_n;
     const int grp = id / per_group, rem_id = id - grp * per_group;
     const int rows_here = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;
@@ -967,6 +966,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     // tiles left over - a last, partly filled round that would cost a full tile time - are cut into `tail_split` k-parts each,
     // so that the round is as many workgroups but 1 / tail_split as long; the parts leave raw fp32 tiles in the workspace
     // for pp_tail_reduce_kernel (fixed summation order: bitwise reproducible).
+    // Staggered start (GemmParams::stagger): every workgroup of a round reaches its epilogue together, and that burst - 164 MB
+    // per round of 256 tiles with an fp32 + residual epilogue - is what the epilogue's time is made of.  Half of the first
+    // round's workgroups (alternate CUs of every XCD under round-robin placement: a speed matter only) start `stagger` x ~4 us
+    // late, so that their epilogues fall into the other half's main loops for the rest of the launch.
+    if (p.stagger > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     if (p.trace && tid == 0) p.trace[blockIdx.x * 4] = wall_clock64();
     int bid = blockIdx.x, kpart = 0;
     const bool partial = bid >= full_tiles;
@@ -979,7 +984,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         kpart = j % tail_split;
     }
     int tm, tn;
-    pp_tile_coords(bid, tiles_m, tiles_n, tm, tn);
+    pp_tile_coords(bid, tiles_m, tiles_n, tm, tn, p.pp_gm);
     const int m0 = tm * 256, n0 = tn * 256;
     const int KT_all = p.K >> 6;
     const int kt0 = partial ? (int)((int64_t)KT_all * kpart / tail_split) : 0;
@@ -1317,17 +1322,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                         *reinterpret_cast<f4 *>(pu + pidx(li, jj * 16 + 4 * g)) = v;
                     }
                 } else {
+                    // (LNA: the 8 LDS reads of this row tile's bias / column-sum values are issued together, ahead of the patch
+                    //  writes: read-wait-compute-write per 16 columns serialised the LDS queue, ~3 us per tile)
+                    f4 b4[LNA ? 4 : 1], c4[LNA ? 4 : 1];
+                    if constexpr (LNA) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            b4[j] = *reinterpret_cast<const f4 *>(cb + j * 16 + 4 * g);
+                            c4[j] = *reinterpret_cast<const f4 *>(cb + 64 + j * 16 + 4 * g);
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f4 v = acc[i][j];
-                        f4 b4 = f4{0.f, 0.f, 0.f, 0.f}, c4 = b4;
-                        if constexpr (LNA) {
-                            b4 = *reinterpret_cast<const f4 *>(cb + j * 16 + 4 * g);
-                            c4 = *reinterpret_cast<const f4 *>(cb + 64 + j * 16 + 4 * g);
-                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if constexpr (LNA) v[r] = __builtin_fmaf(lst[ib & 1][u].y, v[r] - lst[ib & 1][u].x * c4[r], b4[r]);
+                            if constexpr (LNA) v[r] = __builtin_fmaf(lst[ib & 1][u].y, v[r] - lst[ib & 1][u].x * c4[j][r], b4[j][r]);
                             else v[r] += bz[j * 4 + r];
                             if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
                         }
@@ -1439,7 +1449,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
 template <int EPI>
 __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int tiles_m, int tiles_n, int full_tiles, int tail_split) {
     int tm, tn;
-    pp_tile_coords(full_tiles + blockIdx.x, tiles_m, tiles_n, tm, tn);
+    pp_tile_coords(full_tiles + blockIdx.x, tiles_m, tiles_n, tm, tn, p.pp_gm);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = 4 * lane, n = tn * 256 + col;
     const float *base = p.ws + ((int64_t)blockIdx.x * tail_split << 16) + col;
@@ -1558,6 +1568,8 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
                      (p.ldr & 3) == 0 && p.residual;
     if (lnp) *p.ln_done = 1;
     else p.ln_part = nullptr;
+    p.stagger = g_knobs.misc[5];
+    p.pp_gm = g_knobs.pp_gm;
     void (*kern)(GemmParams, int, int, int, int) = gemm_pp_kernel<EPI, false>;
     if (lna) kern = gemm_pp_kernel<EPI, true>;
     const int bm = cdiv(p.M, 256), bn = cdiv(p.N, 256);

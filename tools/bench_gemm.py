@@ -133,6 +133,25 @@ if __name__ == "__main__":
             bench_narrow("down", M, 4096, 14336, "res")
             bench_narrow("qkv", M, 6144, 4096, "slab")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "custom_gm":   # rasterisation group size of gemm_pp_kernel (knob pp_gm)
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"pp_gm", int(sys.argv[2])))
+        bench_tile("dec wgu silu", 6144, 28672, 4096, 2)
+        bench_tile("esm qkv", 32896, 3840, 1280, 0)
+        bench_tile("esm fc1 gelu", 32896, 5120, 1280, 1)
+        bench_tile("projector sw2 M=4096", 4096, 32768, 32768, 0, iters=5)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stagger":   # late start of half of the first round of gemm_pp_kernel (knob misc5, x ~4 us)
+        for st in (0, 2, 4, 6, 8, 0):
+            _cabi.check(lib.opus_debug_knob(model._ctx, b"misc5", st))
+            print(f"== stagger {st}")
+            bench_tile("esm qkv", 32896, 3840, 1280, 0)
+            bench_tile("esm wo +res", 32896, 1280, 1280, 0, True, True)
+            bench_tile("esm fc1 gelu", 32896, 5120, 1280, 1)
+            bench_tile("esm fc2 +res", 32896, 1280, 5120, 0, True, True)
+            bench_tile("dec wo +res", 6144, 4096, 4096, 0, True, True)
+            bench_tile("dec wgu silu", 6144, 28672, 4096, 2)
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"misc5", 0))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tile":
         for M in (32896, 514):
             bench_tile("esm qkv", M, 3840, 1280, 0)

@@ -12,6 +12,9 @@ model = OpusLlamaForCausalLM(cfg, DeviceWeights.synthetic(cfg, 0, dev), dev)
 lib = _cabi.lib()
 M, N, K = (int(x) for x in sys.argv[1:4])
 it = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+for k in sys.argv[5:]:                       # knob=value ... (e.g. pp_gm=4)
+    name, v = k.split("=")
+    _cabi.check(lib.opus_debug_knob(model._ctx, name.encode(), int(v)))
 W = (torch.randn(N, K, device=dev) * 0.02).half()
 A = torch.randn(M, K, device=dev).half()
 out = torch.zeros(M, N, dtype=torch.float16, device=dev)
