@@ -184,7 +184,8 @@ int opus_debug_gemm_slabs(opus_ctx *ctx, const void *d_A, const void *d_W, float
                           int32_t *ks, void *stream);
 /* Process-wide tuning knob of the benchmarks / parity tests (no reference counterpart): "no_stream" = 1 routes the narrow
  * GEMMs of the batched decode step through the round-2 split-K kernels instead of gemm_stream_kernel; "pp_gm" = tile rows
- * per rasterisation group of the big tiled GEMM; "debug_a_tiled" = 1: opus_debug_gemm takes A in fragment order; "misc0".."misc7" scratch.  ctx (may be NULL) drops its captured decode graph. */
+ * per rasterisation group of the big tiled GEMM; "debug_a_tiled" = 1: opus_debug_gemm takes A in fragment order; "no_ln_fusion" = 1: stand-alone normalisation kernels
+ * instead of the norms fused around the big tiled GEMM; "misc0".."misc7" scratch.  ctx (may be NULL) drops its captured decode graph. */
 int opus_debug_knob(opus_ctx *ctx, const char *name, int32_t value);
 /* The row-scale RMSNorm fusion as the decoder issues it (api.cpp prefill / decode_step): X <- X + A W1^T through a GEMM
  * (gemm_stream_kernel at 5..64 rows, else a split-K GEMM) whose epilogue / reduce also writes fp16(X) and per-block sums of squares, then C = epi(rmsnorm(X) W2^T) with

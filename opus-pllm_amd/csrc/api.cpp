@@ -603,7 +603,8 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
     // rstd (acc - mu s) + c2 in its epilogue - no pass over the fp32 stream in between.  Shapes the big kernel does not take
     // (few rows), the first layer, and OPUS_NO_LN_FUSION=1 use the stand-alone normalisation (x - mu) rstd (the affine part
     // lives in the folded weights either way).
-    static const bool no_ln_fusion = getenv("OPUS_NO_LN_FUSION") != nullptr;   // A/B aid
+    static const bool no_ln_env = getenv("OPUS_NO_LN_FUSION") != nullptr;      // A/B aid (also the knob of the same name)
+    const bool no_ln_fusion = no_ln_env || g_knobs.no_ln_fusion;
     const bool qkv_pp = !no_ln_fusion && (D & 255) == 0 && gemm_goes_pp(M, 3 * D);
     const bool fc1_pp = !no_ln_fusion && (D & 255) == 0 && gemm_goes_pp(M, F);
     bool have_stat = false;                        // e_xn = fp16(x), e_stat = (mu, rstd) of the current residual stream
@@ -892,7 +893,8 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
     KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
     // RMSNorm fused around the big tiled GEMM, as the encoder's LayerNorm (GemmParams::ln_* with mu = 0): the wo / down epilogue
     // leaves fp16(x) + per-slab sums of squares, the consuming projection scales its rows by rstd in its epilogue
-    static const bool no_ln_fusion = getenv("OPUS_NO_LN_FUSION") != nullptr;   // A/B aid
+    static const bool no_ln_env = getenv("OPUS_NO_LN_FUSION") != nullptr;      // A/B aid (also the knob of the same name)
+    const bool no_ln_fusion = no_ln_env || g_knobs.no_ln_fusion;
     const bool qkv_pp = !no_ln_fusion && (H & 255) == 0 && (QKV & 255) == 0 && gemm_goes_pp(M, QKV);
     const bool gu_pp = !no_ln_fusion && (H & 255) == 0 && (F & 127) == 0 && gemm_goes_pp(M, 2 * F);
     bool have_stat = false;
@@ -1318,6 +1320,7 @@ extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
     }
     if (!strcmp(name, "no_stream")) g_knobs.no_stream = value;
     else if (!strcmp(name, "debug_a_tiled")) g_knobs.debug_a_tiled = value;
+    else if (!strcmp(name, "no_ln_fusion")) g_knobs.no_ln_fusion = value;
     else if (!strcmp(name, "pp_gm")) { if (value < 1 || value > 64) return fail(OPUS_EBADARG, "pp_gm out of range"); g_knobs.pp_gm = value; }
     else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '7' && !name[5]) g_knobs.misc[name[4] - '0'] = value;
     else return fail(OPUS_EBADARG, "debug_knob: unknown knob '%s'", name);

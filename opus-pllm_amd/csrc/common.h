@@ -164,6 +164,7 @@ hipError_t launch_gemm_stream(const GemmParams &p, hipStream_t s);
 // Run-time tuning knobs (A/B aids; opus_debug_knob sets them, environment variables give the defaults)
 struct Knobs {
     int no_stream = 0;      // 1: narrow decode GEMMs take the round-2 kernels (gemm_wide / gemm_ring / gemm_mid + reduce)
+    int no_ln_fusion = 0;   // 1: stand-alone normalisation kernels instead of the norms fused around gemm_pp_kernel
     int debug_a_tiled = 0;  // 1: opus_debug_gemm takes A in fragment order (GemmParams::a_tiled)
     int pp_gm = 8;          // tile-rows per group of the gemm_pp / gemm_ring rasterisation
     int misc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // scratch knobs for experiments

@@ -492,3 +492,66 @@ def test_two_stage_tokens_match_one_stage_at_full_size(big64):
     a = model.generate(ids, seqs, max_new_tokens=6, pad_token_id=0)
     b = model.generate(ids, seqs, max_new_tokens=6, pad_token_id=0, protein_tokens=two)
     assert (a == b).float().mean() > 0.9                         # near-ties may flip a row; decisive first steps did not
+
+
+def test_fused_norms_match_standalone_kernels(big64):
+    """Rows E2 / D1: the LayerNorm (encoder) and RMSNorm (decoder prefill) fused around the big tiled GEMM - producer epilogue
+    leaves fp16(x) + partial sums, consumer epilogue applies rstd (acc - mu s) + c2 - against the stand-alone normalisation
+    kernels in front of plain GEMMs on the same folded weights: same function, different rounding points."""
+    from opus_pllm_amd import _cabi
+    cfg, model = big64
+    lib = _cabi.lib()
+    seqs = [synth.synth_protein(120 + 3 * i, 300 + i) for i in range(64)]    # 64 x <= 311 tokens: every encoder GEMM on gemm_pp
+    ids = _prompts(cfg, 64)
+    out = {}
+    try:
+        for off in (0, 1):
+            _cabi.check(lib.opus_debug_knob(model._ctx, b"no_ln_fusion", off))
+            pooled = model.encode_seq2embedding(seqs)
+            prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+            emb, mask, _ = model._splice(ids, None, prot, True)
+            lg = model.prefill_logits(emb, mask)
+            out[off] = (pooled, lg)
+    finally:
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"no_ln_fusion", 0))
+    # the knob switches kernels (the finalize launches of the fused form are counted in the same class as the stand-alone norms,
+    # so launch counts do not tell them apart): different rounding points, so not bit-identical
+    assert not torch.equal(out[0][0], out[1][0]) and not torch.equal(out[0][1], out[1][1])
+    rel_p, rel_l = rel_l2(out[0][0], out[1][0]), rel_l2(out[0][1], out[1][1])
+    record("fused_vs_standalone_norms", dict(pooled=rel_p, logits=rel_l))
+    assert rel_p < ROW_VS_BATCH and rel_l < ROW_VS_BATCH_LOGITS, (rel_p, rel_l)
+    decisive = _margin(out[1][1]) > MARGIN_TAU
+    assert torch.equal(out[0][1].argmax(-1)[decisive], out[1][1].argmax(-1)[decisive])
+
+
+def test_b64_left_padded_rows_match_rows_alone(big64):
+    """Row D4 at batch 64 (grouped decode attention, key tiles indexed by absolute cache slot): rows whose prompts are 49
+    positions shorter than the batch's longest are left-padded by more than a whole 32-slot tile; their prefill + decode logits
+    equal those of the row alone (no padding) and their greedy ids agree on decisive steps."""
+    cfg, model = big64
+    seqs = [synth.synth_protein(100 + i, 500 + i) for i in range(64)]
+    rows = [synth.synth_prompt_ids(cfg.dec_vocab, i, n_text=89 if i % 2 == 0 else 40, seq_pos=7) for i in range(64)]
+    ids = opa.left_pad_sequence([torch.tensor(r) for r in rows], 0, batch_first=True)
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    for i in range(1, 64, 2):
+        mask[i, : 89 - 40] = False
+    prot = model.switch_projector_embedding(model.encode_projector_embedding(model.encode_seq2embedding(seqs)))
+    emb, mo, _ = model._splice(ids, mask, prot, True)
+    lg0 = model.prefill_logits(emb, mo)
+    forced = [lg0.argmax(-1)]
+    steps = [lg0]
+    for _ in range(2):
+        steps.append(model.decode_logits(forced[-1]))
+        forced.append(steps[-1].argmax(-1))
+    steps = torch.stack(steps)
+    worst, decisive = 0.0, 0
+    for i in (1, 33, 63):                                        # padded rows
+        e1, m1, _ = model._splice(torch.tensor([rows[i]]), None, prot[i:i + 1], True)
+        one = _teacher_forced(model, e1, m1, torch.stack(forced[:2], 1)[i:i + 1])
+        for s in range(3):
+            worst = max(worst, rel_l2(one[s, 0], steps[s, i]))
+            if float(_margin(steps[s, i:i + 1])) > MARGIN_TAU:
+                decisive += 1
+                assert int(one[s, 0].argmax()) == int(steps[s, i].argmax()), (i, s)
+    record("b64.left_padded_row_vs_alone", dict(logits=worst, decisive=decisive))
+    assert worst < ROW_VS_BATCH_LOGITS and decisive >= 6, (worst, decisive)
