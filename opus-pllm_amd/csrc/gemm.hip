@@ -47,12 +47,12 @@ hipError_t ensure_dyn_lds(const void *fn, size_t bytes) {
 // of the ~40-instruction libm erff; on the 168 M activations of an ESM-2 fc1 GEMM that is 20 % of the kernel.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp): an IEEE division is ~10 instructions
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // (v_rcp_f32, as gelu_erf)
 
 // ------------------------------------------------------------------------------------------------
 // skinny.  Workgroup = PB panels (PB = 2 for the gate/up pair, else 1) x (nwaves / PB) k-parts.

@@ -28,14 +28,17 @@
 // it is one contiguous 1-KB wave access (66 GB/s).  GemmParams::a_tiled selects it; the producers of the decode step
 // (attn_decode_kernel, the embedding kernel, the epilogues that write fp16(x)) write that layout when asked to.
 #include "common.h"
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 namespace opus {
 
 __device__ __forceinline__ float gelu_erf_s(float x) {   // same arithmetic as gemm.hip's gelu_erf
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp): an IEEE division is ~10 instructions
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
@@ -56,6 +59,8 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
     const int nck = c1 - c0;
     const int nsteps = (nck + NW - 1) / NW;
     const int panel0 = blockIdx.x * P;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.trace && tid == 0) p.trace[wg * 8] = wall_clock64();
 
     const half_t *wp[P];
 #pragma unroll
@@ -138,7 +143,9 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
                 if (s + U < nsteps) load(u_tag, s + U);
             }
         });
+        if (p.trace && tid == 0 && s0 == 0) p.trace[wg * 8 + 1] = wall_clock64();     // (the first sets have landed)
     }
+    if (p.trace && tid == 0) p.trace[wg * 8 + 2] = wall_clock64();
 
     // ---- combine the NW partial tiles through LDS, in wave order ----
     f4 *red = reinterpret_cast<f4 *>(smem);          // [NW][TILES][64] f4
@@ -147,9 +154,10 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
 #pragma unroll
         for (int i = 0; i < MT; ++i) red[(wave * TILES + j * MT + i) * 64 + lane] = acc[j][i];
     __syncthreads();
+    if (p.trace && tid == 0) p.trace[wg * 8 + 4] = wall_clock64();
     const int npanels = p.N >> 4;
     // the GEMM epilogue on the finished sums of one tile: this lane holds columns n .. n + 3 of row m
-    auto finish = [&](int tile, f4 v) {
+    auto finish = [&](int tile, f4 v, const float4 *rpre = nullptr) {    // rpre: the residual values, loaded earlier
         const int j = tile / MT, i = tile - j * MT;
         const int m = 16 * i + li;
         const int panel = panel0 + j;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf_s(v[r]);
         }
         if (p.residual && live) {
-            const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + n);
+            const float4 rr = rpre ? *rpre : *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + n);
             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
         }
         if (live) {
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
         f4 v = red[tile * 64 + lane];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[(w * TILES + tile) * 64 + lane];
+        if (p.trace && tid == 0 && tile == 0) p.trace[wg * 8 + 5] = wall_clock64();
         if (ksplit == 1) { finish(tile, v); continue; }
         const int j = tile / MT, i = tile - j * MT;
         const int m = 16 * i + li, n = (panel0 + j) * 16 + 4 * g;
@@ -195,37 +204,62 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
         if (combine) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, v), wrs, off, 0, 16);   // aux 16 = sc1
         else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, v), wrs, off, 0, 0);
     }
+    if (p.trace && tid == 0) p.trace[wg * 8 + 3] = wall_clock64();
     if (!combine) return;
     // ---- in-launch combine of the k-parts (cdna_hip_programming.md "In-launch split-K reduction", sc1 form) ----
     // every wave has drained its write-through slab stores; one lane draws a ticket; the workgroup that draws the last one
     // reads all slabs of its column group with sc1 loads (L1 bypassed), sums them in k-part order - the same sums whichever
     // workgroup arrives last - and runs the epilogue; it also re-arms the counter for the next launch.
+    // (the residual values of the tiles this wave would finish are requested before the drain: only the workgroup that arrives
+    //  last uses them, and nobody writes them before it does - its own epilogue is the only writer of these columns)
+    constexpr int TPW = (TILES + NW - 1) / NW;
+    float4 rpre[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + t * NW;
+        const int j = tile / MT, i = tile - j * MT;
+        const int m = 16 * i + li, n = (panel0 + j) * 16 + 4 * g;
+        rpre[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.residual && tile < TILES && m < p.M) rpre[t] = *reinterpret_cast<const float4 *>(p.residual + (int64_t)m * p.ldr + n);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int *flag = reinterpret_cast<int *>(smem + (size_t)NW * TILES * 1024);
+    if (p.trace && tid == 0) p.trace[wg * 8 + 6] = wall_clock64();       // (slab stores drained)
     if (tid == 0) *flag = __hip_atomic_fetch_add(p.combine_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    if (p.trace && tid == 0) p.trace[wg * 8 + 7] = wall_clock64();       // (ticket drawn)
     if (*flag != ksplit - 1) return;                     // uniform
     if (tid == 0) __hip_atomic_store(p.combine_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int tile = wave; tile < TILES; tile += NW) {
-        const int j = tile / MT, i = tile - j * MT;
-        int m = 16 * i + li;
-        m = m < p.M ? m : p.M - 1;
-        const int n = (panel0 + j) * 16 + 4 * g;
-        u4s t[4];
-        f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < ksplit; k0 += 4) {         // 4 slabs requested at a time, added in k-part order
+    // all slab loads of this wave's tiles are requested together (k-parts in groups of 4), then added in k-part order
+    f4 vsum[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) vsum[t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < ksplit; k0 += 4) {
+        u4s tl[TPW][4];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tile = wave + t * NW < TILES ? wave + t * NW : wave;
+            const int j = tile / MT, i = tile - j * MT;
+            int m = 16 * i + li;
+            m = m < p.M ? m : p.M - 1;
+            const int n = (panel0 + j) * 16 + 4 * g;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int kk = k0 + u < ksplit ? k0 + u : ksplit - 1;
-                t[u] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)((((int64_t)kk * p.M + m) * p.N + n) * 4), 0, 16);
+                tl[t][u] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)((((int64_t)kk * p.M + m) * p.N + n) * 4), 0, 16);
             }
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (k0 + u < ksplit) v += __builtin_bit_cast(f4, t[u]);
-        }
-        finish(tile, v);
+                if (k0 + u < ksplit) vsum[t] += __builtin_bit_cast(f4, tl[t][u]);
     }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (wave + t * NW < TILES) finish(wave + t * NW, vsum[t], &rpre[t]);
+    if (p.trace && tid == 0) p.trace[wg * 8 + 3] = wall_clock64();       // (the combining workgroup: its real end)
 }
 
 // ---- launcher ----
@@ -303,6 +337,43 @@ static hipError_t launch_stream_t(const GemmParams &p_in, const StreamPlan &pl, 
     else p.xh_out = nullptr;
     if (pl.ks > 1) p.row_ssq = nullptr;
     if (p.ks_out) *p.ks_out = pl.ks;
+    static const bool trace = getenv("OPUS_STREAM_TRACE") != nullptr;   // tuning aid: per-workgroup section stamps on stderr
+    if (trace) {
+        static long long *tb = nullptr;
+        const int nwg = npanels / P * pl.ks;
+        if (!tb) (void)hipMalloc((void **)&tb, (size_t)1024 * 8 * sizeof(long long));
+        if (tb && nwg <= 1024) {
+            GemmParams q = p;
+            q.trace = tb;
+            for (int rep = 0; rep < 3; ++rep)      // (the third launch is reported: code and activations warm, weights from HBM if > caches)
+                hipLaunchKernelGGL((gemm_stream_kernel<MT, P, NT, U, EPI>), dim3(npanels / P, pl.ks), dim3(NT), lds, s, q, pl.ks);
+            (void)hipStreamSynchronize(s);
+            std::vector<long long> h((size_t)nwg * 8);
+            (void)hipMemcpy(h.data(), tb, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            long long t0 = h[0];
+            for (int i = 0; i < nwg; ++i) t0 = std::min(t0, h[8 * i]);
+            std::vector<double> st, fl, ml, en, ba, su, dr, tk;
+            for (int i = 0; i < nwg; ++i) {
+                st.push_back((h[8 * i] - t0) * 0.01); fl.push_back((h[8 * i + 1] - h[8 * i]) * 0.01);
+                ml.push_back((h[8 * i + 2] - t0) * 0.01); en.push_back((h[8 * i + 3] - t0) * 0.01);
+                ba.push_back((h[8 * i + 4] - t0) * 0.01); su.push_back((h[8 * i + 5] - t0) * 0.01);
+                if (combine) { dr.push_back((h[8 * i + 6] - t0) * 0.01); tk.push_back((h[8 * i + 7] - t0) * 0.01); }
+            }
+            auto q3 = [](std::vector<double> v, const char *nm) {
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "   %-34s min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", nm, v.front(), v[v.size() / 10],
+                        v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+            };
+            fprintf(stderr, "[stream trace] M=%d N=%d K=%d P=%d ks=%d nt=%d wgs=%d tiled=%d combine=%d\n", p.M, p.N, p.K, P, pl.ks, NT, nwg, p.a_tiled, (int)combine);
+            q3(st, "start after the first start");
+            q3(fl, "start -> first sets multiplied");
+            q3(ml, "main loop end, wave 0 (after first start)");
+            q3(ba, "all waves' partial tiles in LDS");
+            q3(su, "wave 0's first tile summed");
+            if (combine) { q3(dr, "slab stores drained"); q3(tk, "ticket drawn"); }
+            q3(en, "end (after first start)");
+        }
+    }
     OPUS_LAUNCH(KC_STREAM, (gemm_stream_kernel<MT, P, NT, U, EPI>), dim3(npanels / P, pl.ks), dim3(NT), lds, s, p, pl.ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || pl.ks == 1 || p_in.slab_only || combine) return e;

@@ -133,6 +133,27 @@ if __name__ == "__main__":
             bench_narrow("down", M, 4096, 14336, "res")
             bench_narrow("qkv", M, 6144, 4096, "slab")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "strace":    # run with OPUS_STREAM_TRACE=1: per-workgroup section stamps of gemm_stream_kernel
+        import ctypes as C
+        for name, N, K, kind, tiled in (("wo", 4096, 4096, "res", 1), ("down", 4096, 14336, "res", 1), ("qkv", 6144, 4096, "slab", 1)):
+            M = 64
+            w = [(torch.randn(N * K, device=dev) * 0.02).half() for _ in range(12)]     # (beyond the Infinity Cache together)
+            A = torch.randn(M, K, device=dev).half()
+            X = torch.randn(M, N, device=dev)
+            ks = C.c_int32(0)
+            _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", tiled))
+            print(f"== {name}", flush=True)
+            for i in range(2):
+                for ww in w:
+                    ww.add_(0)                                                             # sweep the caches
+                if kind == "res":
+                    _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), w[i].data_ptr(), None, X.data_ptr(), X.data_ptr(), M, N, K, 0, 1, None))
+                else:
+                    _cabi.check(lib.opus_debug_gemm_slabs(model._ctx, A.data_ptr(), w[i].data_ptr(), None, M, N, K, C.byref(ks), None))
+                torch.cuda.synchronize()
+            del w
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 0))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "custom_gm":   # rasterisation group size of gemm_pp_kernel (knob pp_gm)
         _cabi.check(lib.opus_debug_knob(model._ctx, b"pp_gm", int(sys.argv[2])))
         bench_tile("dec wgu silu", 6144, 28672, 4096, 2)
@@ -151,6 +172,14 @@ if __name__ == "__main__":
             bench_tile("dec wo +res", 6144, 4096, 4096, 0, True, True)
             bench_tile("dec wgu silu", 6144, 28672, 4096, 2)
         _cabi.check(lib.opus_debug_knob(model._ctx, b"misc5", 0))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pptrace":   # run with OPUS_PP_TRACE=1: section times of gemm_pp_kernel per shape
+        bench_tile("esm qkv", 32896, 3840, 1280, 0, iters=2)
+        bench_tile("esm wo +res", 32896, 1280, 1280, 0, True, True, iters=2)
+        bench_tile("esm fc1 gelu", 32896, 5120, 1280, 1, iters=2)
+        bench_tile("esm fc2 +res", 32896, 1280, 5120, 0, True, True, iters=2)
+        bench_tile("dec qkv", 6144, 6144, 4096, 0, iters=2)
+        bench_tile("dec wgu silu", 6144, 28672, 4096, 2, iters=2)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tile":
         for M in (32896, 514):
