@@ -37,6 +37,28 @@ __device__ __forceinline__ int vswz(int row) {
     return 0;                                        //  32-B rows: 8 rows = one bank row
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// maximum over the lane pairs (l, l ^ 16) and (l, l ^ 32) with gfx950's row swaps instead of ds_bpermute round trips through
+// the LDS pipe: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second, so
+// with both operands holding x the results are [x0 x0 x2 x2] and [x1 x1 x3 x3]; v_permlane32_swap does the same with halves.
+// (s_nop 1: the operands come from a VALU instruction the assembler cannot see)
+__device__ __forceinline__ float xor16_max(float x) {
+    float a = x, b = x, r;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void xor32_pair(float x, float &a, float &b) {
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
 
@@ -110,23 +132,28 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     constexpr int VL = VN >= 256 ? VN / 256 : 1;
     static_assert(KL >= 1, "tile too small for 256 threads");
     h8 kreg[KL], vreg[VL];
+    // through buffer descriptors that end with the batch row's last key: rows >= T of the last tile read as zeros without a
+    // clamp, and a tile's addresses are the thread's fixed byte offsets plus one wave-uniform term (no 64-bit address
+    // arithmetic per tile: that was ~30 VALU instructions of every tile, 8 of them quarter-rate multiplies)
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (int)(((int64_t)(p.T - 1) * p.k_st + HD) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (int)(((int64_t)(p.T - 1) * p.v_st + HD) * 2), 0x00020000);
+    int koff[KL], voff[VL];
+#pragma unroll
+    for (int u = 0; u < KL; ++u) {
+        const int i = tid + 256 * u, r = i / CH, c = i % CH;
+        koff[u] = c * 8 < HD ? (int)((r * p.k_st + c * 8) * 2) : 0x7ffffff0;        // (zero padding of head_dim 16: out of range)
+    }
+#pragma unroll
+    for (int u = 0; u < VL; ++u) {
+        const int i = tid + 256 * u, r = i / VC, c = i % VC;
+        voff[u] = i < VN ? (int)((r * p.v_st + c * 8) * 2) : 0x7ffffff0;
+    }
     auto load_tile = [&](int kt) {
+        const int kb = kt * (int)p.k_st * 2, vb = kt * (int)p.v_st * 2;               // (wave-uniform)
 #pragma unroll
-        for (int u = 0; u < KL; ++u) {
-            const int i = tid + 256 * u, r = i / CH, c = i % CH;
-            int kr = kt + r;
-            kr = kr < p.T ? kr : p.T - 1;
-            kreg[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (c * 8 < HD) kreg[u] = *reinterpret_cast<const h8 *>(Kb + (int64_t)kr * p.k_st + c * 8);
-        }
+        for (int u = 0; u < KL; ++u) kreg[u] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(krs, koff[u] + kb, 0, 0));
 #pragma unroll
-        for (int u = 0; u < VL; ++u) {
-            const int i = tid + 256 * u, r = i / VC, c = i % VC;
-            int kr = kt + r;
-            kr = kr < p.T ? kr : p.T - 1;
-            vreg[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (i < VN) vreg[u] = *reinterpret_cast<const h8 *>(Vb + (int64_t)kr * p.v_st + c * 8);
-        }
+        for (int u = 0; u < VL; ++u) vreg[u] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[u] + vb, 0, 0));
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -147,11 +174,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         if (k_lo + KB < k_hi) load_tile(k_lo + KB);
     }
     __syncthreads();
-    int buf = 0;
-    for (int kt = k_lo; kt < k_hi; kt += KB, buf ^= 1) {
-        // the tile's compute for the first NSUB 16-key subtiles (4 = the whole tile; fewer for a short last tile: T = 514 ends
-        // with a tile of 2 keys, which costs a quarter of a full one this way)
-        auto tile_body = [&](auto nsub_tag) {
+    // the tile's compute for the first NSUB 16-key subtiles (4 = the whole tile; fewer for a short last tile: T = 514 ends
+    // with a tile of 2 keys, which costs a quarter of a full one this way)
+    auto tile_body = [&](auto nsub_tag, int kt, int buf) {
+        {
             constexpr int NSUB = decltype(nsub_tag)::value, NJ = (NSUB + 1) / 2;
             const half_t *tK = sK[buf], *tV = sV[buf];
             // ---- S^T = K Q^T : NSUB key subtiles x QT query tiles ----
@@ -170,63 +196,93 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                 }
             }
             // ---- mask + online softmax: lane (li, g) owns query qw + 16 t + li, keys kt + 16 n + 4 g + r ----
-            // interior: every key of the tile is visible to every query row of this wave (wave-uniform): no masking code
+            // interior: every key of the tile is visible to every query row of this wave (wave-uniform): no masking code.
+            // A boundary tile masks the scores in place and then runs the SAME softmax code (one copy of it: two copies
+            // merged through ~40 register moves per tile)
             const bool interior = kt >= kstart && kt + KB <= kend && (!CAUSAL || kt + KB - 1 <= qw);
-            h8 pf[QT][2];
-            auto softmax = [&](auto masked_tag) {
-                constexpr bool MASKED = decltype(masked_tag)::value;
+            if (__builtin_expect(!interior, 0)) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    if (MASKED) {                                        // tiles that touch a padding / causal boundary
-                        const int qi = qw + 16 * t + li;
-#pragma unroll
-                        for (int n = 0; n < NSUB; ++n)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int kj = kt + 16 * n + 4 * g + r;
-                                bool vis = kj >= kstart && kj < kend;
-                                if (CAUSAL) vis = vis && kj <= qi;
-                                s[t][n][r] = vis ? s[t][n][r] : -INFINITY;
-                            }
-                    }
-                    // row maximum of the raw scores (the scale is positive): 16 in-lane values, then the four lane groups
-                    float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
-#pragma unroll
-                    for (int n = 1; n < NSUB; ++n) mx = fmaxf(fmaxf(mx, fmaxf(s[t][n][0], s[t][n][1])), fmaxf(s[t][n][2], s[t][n][3]));
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    const float mnew = fmaxf(mrow[t], mx);
-                    const float msafe = MASKED ? (mnew == -INFINITY ? 0.f : mnew) : mnew;   // interior tiles: finite
-                    const float msc = msafe * sc;
-                    if (!__all(mnew == mrow[t])) {                       // (wave-uniform) some row's maximum grew: rescale
-                        const float alpha = __builtin_amdgcn_exp2f((mrow[t] - msafe) * sc);   // 0 when mrow = -inf
-                        lrow[t] *= alpha;
-#pragma unroll
-                        for (int n = 0; n < NO; ++n) o[t][n] *= alpha;
-                        mrow[t] = mnew;
-                    }
-                    float rs = 0.f;
+                    const int qi = qw + 16 * t + li;
 #pragma unroll
                     for (int n = 0; n < NSUB; ++n)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][n][r], sc, -msc));
-                            s[t][n][r] = e;
-                            rs += e;
+                            const int kj = kt + 16 * n + 4 * g + r;
+                            bool vis = kj >= kstart && kj < kend;
+                            if (CAUSAL) vis = vis && kj <= qi;
+                            s[t][n][r] = vis ? s[t][n][r] : -INFINITY;
                         }
-                    lrow[t] += rs;                                       // this lane's keys only: summed over g at the end
-                    // P^T fragments: 32-key step j = subtiles 2j, 2j+1; element e -> key 16 (2j + e/4) + 4g + e%4
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const bool two = 2 * j + 1 < NSUB;               // (odd NSUB: the second subtile of the last step is absent)
-                        pf[t][j] = h8{(half_t)s[t][2 * j][0], (half_t)s[t][2 * j][1], (half_t)s[t][2 * j][2], (half_t)s[t][2 * j][3],
-                                      two ? (half_t)s[t][two ? 2 * j + 1 : 0][0] : (half_t)0.f, two ? (half_t)s[t][two ? 2 * j + 1 : 0][1] : (half_t)0.f,
-                                      two ? (half_t)s[t][two ? 2 * j + 1 : 0][2] : (half_t)0.f, two ? (half_t)s[t][two ? 2 * j + 1 : 0][3] : (half_t)0.f};
-                    }
                 }
-            };
-            if (__builtin_expect(interior, 1)) softmax(std::false_type{});
-            else softmax(std::true_type{});
+            }
+            h8 pf[QT][2];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                // row maximum of the raw scores (the scale is positive): 4 NSUB in-lane values (v_max3 chain), then the four
+                // lane groups with two row swaps (v_permlane16_swap / v_permlane32_swap: no LDS round trip)
+                float ma, mb;
+                if constexpr (NSUB == 4) {
+                    // one asm block (the compiler pads every asm statement with s_nop): 16 in-lane values, then the rows
+                    asm volatile(
+                        "v_max3_f32 %0, %2, %3, %4\n\t"
+                        "v_max3_f32 %0, %0, %5, %6\n\t"
+                        "v_max3_f32 %0, %0, %7, %8\n\t"
+                        "v_max3_f32 %0, %0, %9, %10\n\t"
+                        "v_max3_f32 %0, %0, %11, %12\n\t"
+                        "v_max3_f32 %0, %0, %13, %14\n\t"
+                        "v_max3_f32 %0, %0, %15, %16\n\t"
+                        "v_max_f32 %0, %0, %17\n\t"
+                        "v_mov_b32 %1, %0\n\t"
+                        "s_nop 1\n\t"
+                        "v_permlane16_swap_b32 %0, %1\n\t"
+                        "v_max_f32 %0, %0, %1\n\t"
+                        "v_mov_b32 %1, %0\n\t"
+                        "s_nop 1\n\t"
+                        "v_permlane32_swap_b32 %0, %1"
+                        : "=&v"(ma), "=&v"(mb)
+                        : "v"(s[t][0][0]), "v"(s[t][0][1]), "v"(s[t][0][2]), "v"(s[t][0][3]), "v"(s[t][1][0]), "v"(s[t][1][1]),
+                          "v"(s[t][1][2]), "v"(s[t][1][3]), "v"(s[t][2][0]), "v"(s[t][2][1]), "v"(s[t][2][2]), "v"(s[t][2][3]),
+                          "v"(s[t][3][0]), "v"(s[t][3][1]), "v"(s[t][3][2]), "v"(s[t][3][3]));
+                } else {
+                    float mx = max3(s[t][0][0], s[t][0][1], s[t][0][2]);
+                    mx = NSUB > 1 ? max3(mx, s[t][0][3], s[t][1 % NSUB][0]) : fmaxf(mx, s[t][0][3]);
+                    if constexpr (NSUB > 1) mx = fmaxf(max3(mx, s[t][1 % NSUB][1], s[t][1 % NSUB][2]), s[t][1 % NSUB][3]);
+                    mx = xor16_max(mx);
+                    xor32_pair(mx, ma, mb);
+                }
+                const float mnew = max3(mrow[t], ma, mb);
+                const float msafe = mnew == -INFINITY ? 0.f : mnew;       // (rows with no visible key so far)
+                const float msc = msafe * sc;
+                if (!__all(mnew == mrow[t])) {                           // (wave-uniform) some row's maximum grew: rescale
+                    const float alpha = __builtin_amdgcn_exp2f((mrow[t] - msafe) * sc);   // 0 when mrow = -inf
+                    lrow[t] *= alpha;
+#pragma unroll
+                    for (int n = 0; n < NO; ++n) o[t][n] *= alpha;
+                    mrow[t] = mnew;
+                }
+                // exponentials: the arguments and the row sum two at a time (v_pk_fma_f32 / v_pk_add_f32)
+                const f2 sc2 = f2{sc, sc}, msc2 = f2{msc, msc};
+                f2 rs2 = f2{0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < NSUB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f2 a = f2{s[t][n][r], s[t][n][r + 1]} * sc2 - msc2;
+                        const f2 e = f2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                        s[t][n][r] = e[0];
+                        s[t][n][r + 1] = e[1];
+                        rs2 += e;
+                    }
+                lrow[t] += rs2[0] + rs2[1];                              // this lane's keys only: summed over g at the end
+                // P^T fragments: 32-key step j = subtiles 2j, 2j+1; element e -> key 16 (2j + e/4) + 4g + e%4
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const bool two = 2 * j + 1 < NSUB;                   // (odd NSUB: the second subtile of the last step is absent)
+                    pf[t][j] = h8{(half_t)s[t][2 * j][0], (half_t)s[t][2 * j][1], (half_t)s[t][2 * j][2], (half_t)s[t][2 * j][3],
+                                  two ? (half_t)s[t][two ? 2 * j + 1 : 0][0] : (half_t)0.f, two ? (half_t)s[t][two ? 2 * j + 1 : 0][1] : (half_t)0.f,
+                                  two ? (half_t)s[t][two ? 2 * j + 1 : 0][2] : (half_t)0.f, two ? (half_t)s[t][two ? 2 * j + 1 : 0][3] : (half_t)0.f};
+                }
+            }
             // ---- O^T += V^T P^T : A = V^T[dim 16 n + li][key(g, e)] by two transposing reads per fragment ----
             // ds_read_b64_tr_b16: lane i of a 16-lane group supplies the address of row (i >> 2), columns 4 (i & 3) .. + 3 of
             // a 4-row x 16-column block and receives column i of the four rows
@@ -245,20 +301,32 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 #pragma unroll
                     for (int t = 0; t < QT; ++t) o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][j], o[t][n], 0, 0, 0);
                 }
-        };
-        if (wave_live) {
-            const int rem = k_hi - kt;                                   // keys of this tile below k_hi (wave-uniform)
-            if (rem > 32) tile_body(std::integral_constant<int, 4>{});
-            else if (rem > 16) tile_body(std::integral_constant<int, 2>{});
-            else tile_body(std::integral_constant<int, 1>{});
         }
-        // next tile: registers -> the other LDS buffer (its last readers passed the previous barrier), then fetch the one after
-        if (kt + KB < k_hi) {
-            store_tile(buf ^ 1);
-            if (kt + 2 * KB < k_hi) load_tile(kt + 2 * KB);
+    };
+    // The loop over whole tiles has ONE body (the short last tile is peeled off behind it, and the waves past the last query,
+    // which only help with the staging, run their own copy of the loop): with the three tile lengths and the idle case merging
+    // inside one loop body the accumulators went through ~20 register moves per tile.
+    auto run = [&](auto live_tag) {
+        constexpr bool LIVE = decltype(live_tag)::value;
+        int kt = k_lo, buf = 0;
+        for (; k_hi - kt > 32; kt += KB, buf ^= 1) {
+            if constexpr (LIVE) tile_body(std::integral_constant<int, 4>{}, kt, buf);
+            // next tile: registers -> the other LDS buffer (its last readers passed the previous barrier), then fetch the one after
+            if (kt + KB < k_hi) {
+                store_tile(buf ^ 1);
+                if (kt + 2 * KB < k_hi) load_tile(kt + 2 * KB);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+        if constexpr (LIVE) {
+            if (kt < k_hi) {                                             // (the last tile: nothing is staged behind it)
+                if (k_hi - kt > 16) tile_body(std::integral_constant<int, 2>{}, kt, buf);
+                else tile_body(std::integral_constant<int, 1>{}, kt, buf);
+            }
+        }
+    };
+    if (wave_live) run(std::true_type{});
+    else run(std::false_type{});
 
     // ---- epilogue: O / l -> fp16 [b, t, h*HD + d]; lane (li, g) holds dims 16 n + 4 g + r of query li ----
     if (!wave_live) return;
@@ -288,12 +356,14 @@ static hipError_t launch_qt(const AttnParams &p, hipStream_t s) {
 }
 template <int HD>
 static hipError_t launch_hd(const AttnParams &p, hipStream_t s) {
-    // Measured (tools/bench_attn.py ab, one MI355X, both forms in one process): one query tile per wave wins everywhere - it
-    // halves the registers (4 instead of 2 waves per SIMD at head_dim 64, 2 instead of 1 at 128), which matters more to this
-    // latency-bound loop than sharing the K / V fragment reads between two tiles: 64 x 514 x 20 heads x 64: 209-215 vs 267-272 us;
-    // 32 x 1026 x 40 x 64: 729 vs 737 us; batch-64 decoder prefill (96 positions, head_dim 128, causal): 50 vs 75 us; batch 1:
-    // 11 vs 18 us and 6 vs 10 us.  The two-tile form stays instantiated for A/B (knob misc3).
-    bool one = true;
+    // Measured (tools/bench_attn.py ab, one MI355X, both forms in one process, round 3 after the softmax clean-up: one copy of
+    // the softmax code, v_max3 chain + row swaps, packed fma / add, buffer-descriptor staging).  Two query tiles per wave
+    // share every K / V fragment read, the tile staging and the barrier between 32 instead of 16 queries per wave (156 VGPRs:
+    // 3 waves per SIMD): 64 x 514 x 20 heads x 64: 163 vs 222 us (530 vs 390 TFLOP/s; T = 512: 137 vs 188 us = 625 TFLOP/s);
+    // 32 x 1026 x 40 x 64: 527 vs 635 us (655 TFLOP/s).  One tile per wave (104 VGPRs: 4 waves per SIMD, twice the
+    // workgroups) stays ahead where the grid is small (batch 1: 12.6 vs 13.8 us) and at head_dim 128, where two tiles need
+    // 240 VGPRs (batch-64 decoder prefill, 96 positions, causal: 47.8 vs 50.6 us; batch 1: 7.0 vs 8.6 us).
+    bool one = !(HD <= 64 && (int64_t)p.B * p.heads * cdiv(p.T, 128) >= 512);
     if (g_knobs.misc[3]) one = !one;                                 // A/B aid
     return one ? launch_qt<HD, 1>(p, s) : launch_qt<HD, 2>(p, s);
 }
@@ -303,6 +373,7 @@ hipError_t launch_attn_prefill(const AttnParams &p, hipStream_t s) {
     // the 8-byte output stores and 16-byte operand loads need these alignments (every caller of the path satisfies them)
     if ((p.o_st & 3) || (p.o_sb & 3) || (p.q_st & 7) || (p.k_st & 7) || (p.v_st & 7) || (p.q_sb & 7) || (p.k_sb & 7) || (p.v_sb & 7))
         return hipErrorInvalidValue;
+    if ((int64_t)p.T * (p.k_st > p.v_st ? p.k_st : p.v_st) * 2 >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit buffer offsets
     switch (p.head_dim) {
         case 16: return launch_hd<16>(p, s);
         case 32: return launch_hd<32>(p, s);
