@@ -22,7 +22,10 @@
 // rotary (cos, sin) row of each batch row's position comes from a per-step table cs_row[b] written once per decode step by
 // the embedding kernel instead of from the position table behind (step, kstart).
 #include "common.h"
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 namespace opus {
@@ -46,8 +49,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     float *stats = pw + 4 * GP * 32;
     float *red = stats + 4 * GP * 2;
 
+    // every kernel argument the staging phase needs in ONE scalar round trip: left to itself the compiler fetches them in two
+    // batches (the second one just before the first vector load), i.e. two dependent misses before any data is requested
+    asm volatile("" ::"s"(p.qkv), "s"(p.slabs), "s"(p.slab_stride), "s"(p.row_ssq), "s"(p.bias), "s"(p.cs_row), "s"(p.kstart), "s"(p.step),
+                 "s"(p.kc), "s"(p.vc), "s"(p.cache_sb), "s"(p.cache_sh), "s"(p.out));
+    asm volatile("" ::"s"(p.ks), "s"(p.row_nblk), "s"(p.eps), "s"(p.K), "s"(p.T0), "s"(p.nh), "s"(p.nkv), "s"(p.ctx_cap), "s"(p.scale), "s"(p.out_tiled));
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.trace && tid == 0) p.trace[wgid * 8] = wall_clock64();
     const int g = lane >> 4, li = lane & 15;
     const int G = p.nh / p.nkv;
     const int h0 = blockIdx.x * GP;                 // first query head of this workgroup
@@ -57,7 +67,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     half_t *vcb = p.vc + b * p.cache_sb + kvh * p.cache_sh;
     const int64_t ld = (int64_t)(p.nh + 2 * p.nkv) * HD;
 
-    // ---- this wave's first tile (K fragments + V rows of absolute slots 32 wave ..): requested before anything else ----
+    // ---- this wave's first tile (K fragments + V rows of absolute slots 32 wave ..): requested inside stage(), right behind
+    // the new token's operands ----
     h8 kf[2][KS], vr[KPK];
     const int dv = lane % DV, kp = lane / DV;
     const int last_slot = p.ctx_cap - 1;
@@ -81,13 +92,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             vr[i] = *reinterpret_cast<const h8 *>(vcb + (int64_t)j * HD + dv * 8);
         }
     };
-    if (32 * wave < p.ctx_cap) load_tile(wave);
-    const int slot = p.T0 + *p.step;
-    const int kstart = p.kstart[b];
-    const int t_first = kstart >> 5;                // first tile with a visible key
-    const int t_end = (slot + 31) >> 5;             // cached keys are slots kstart .. slot-1; the new key comes from LDS
-    const int ntiles = t_end > t_first ? t_end - t_first : 0;
-    const int new_wave = ntiles & 3;                // the wave with the fewest tiles also takes the new key
+    // *step and kstart[b] through the SCALAR cache (constant address space: s_load, its own counter): as vector loads their
+    // first use drained every vector load issued before them.  They are requested inside stage(), BEHIND the vector loads
+    // (scheduling barrier): placed here the compiler waited for them - a second scalar round trip behind the kernel
+    // arguments' - before it issued the first vector load.
+    typedef const __attribute__((address_space(4))) int32_t *cint_p;
+    int slot = 0, kstart = 0;
 
     // ---- the new token's q / k / v (optionally: sum of the QKV GEMM's k-part slabs, RMSNorm row scale, bias), rotary on
     // the query heads and the key; stage them in LDS and append k, v to the cache ----
@@ -101,12 +111,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = 64 * u + lane;
-            tq[u] = p.row_ssq[(int64_t)b * p.row_nblk + (j < p.row_nblk ? j : p.row_nblk - 1)];
-            tq[u] = j < p.row_nblk ? tq[u] : 0.f;
+            tq[u] = p.row_ssq[(int64_t)b * p.row_nblk + (j < p.row_nblk ? j : p.row_nblk - 1)];   // (masked where it is used)
         }
     }
     auto finish_rstd = [&]() {                       // called behind the requests of stage(): one round trip for everything
         if (!p.row_ssq) return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tq[u] = 64 * u + lane < p.row_nblk ? tq[u] : 0.f;
         float q = (tq[0] + tq[1]) + (tq[2] + tq[3]);
         for (int j0 = 256; j0 < p.row_nblk; j0 += 256) {          // (more than 256 blocks: residual streams wider than 4096)
             float t[4];
@@ -163,6 +174,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         } else {
             tv[0] = (float)p.qkv[b * ld + vcol];
         }
+        // this wave's first key tile is requested BEHIND the new token's operands (vector-memory results return in issue
+        // order): the ~29 MB of cached K / V of a batch-64 step stream in for ~6 us - HBM-bound - and the rotary / staging
+        // work below runs underneath instead of behind them
+        if (32 * wave < p.ctx_cap) load_tile(wave);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = p.T0 + *(cint_p)p.step;
+        kstart = ((cint_p)p.kstart)[b];
         finish_rstd();
         // projection output rounded to fp16, as the unfused GEMM stores it
         auto fin = [&](const float (&t)[NT], float bias) -> float {
@@ -212,6 +230,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         case 7: stage(std::integral_constant<int, 7>{}); break;
         default: stage(std::integral_constant<int, 8>{}); break;   // launch_attn_decode rejects ks > 8
     }
+    const int t_first = kstart >> 5;                // first tile with a visible key
+    const int t_end = (slot + 31) >> 5;             // cached keys are slots kstart .. slot-1; the new key comes from LDS
+    const int ntiles = t_end > t_first ? t_end - t_first : 0;
+    const int new_wave = ntiles & 3;                // the wave with the fewest tiles also takes the new key
     if (HD < HDP) {                                  // zero padding of the 32-wide MFMA k extent
         for (int i = tid; i < (GP + 1) * (HDP - HD); i += 256) {
             const int j = i / (HDP - HD), d = HD + i % (HDP - HD);
@@ -219,7 +241,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             else sk[d] = (half_t)0.f;
         }
     }
+    if (p.trace && tid == 0) p.trace[wgid * 8 + 1] = wall_clock64();       // (this wave's q / k / v staged)
     __syncthreads();
+    if (p.trace && tid == 0) p.trace[wgid * 8 + 2] = wall_clock64();
 
     // query fragments: B operand, column li = head (zero beyond GP)
     h8 qf[KS];
@@ -315,6 +339,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         tile(0, 1);
     }
 
+    if (p.trace && tid == 0) p.trace[wgid * 8 + 3] = wall_clock64();       // (wave 0's key tiles done)
     // ---- publish (m, l) per head and the partial outputs; combine ----
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -329,6 +354,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         *reinterpret_cast<f4 *>(dst + 4) = f4{acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
     }
     __syncthreads();
+    if (p.trace && tid == 0) p.trace[wgid * 8 + 4] = wall_clock64();
     for (int i = tid; i < GP * HD; i += 256) {
         const int h = i / HD, d = i % HD;
         float M = -INFINITY;
@@ -347,6 +373,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         const int kcol = (h0 + h) * HD + d;             // column of the [B, nh HD] context matrix
         p.out[p.out_tiled ? tiled_off(b, kcol, p.nh * HD) : (int64_t)b * p.nh * HD + kcol] = (half_t)(num / den);
     }
+    if (p.trace && tid == 0) p.trace[wgid * 8 + 5] = wall_clock64();
 }
 
 template <int HD, int GP>
@@ -358,6 +385,33 @@ static hipError_t launch_t(const AttnDecodeParams &p, int B, hipStream_t s) {
     if (lds > 48 * 1024) {
         hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&attn_decode_kernel<HD, GP>), lds);
         if (ea != hipSuccess) return ea;
+    }
+    static const bool trace = getenv("OPUS_ATTN_TRACE") != nullptr;     // tuning aid: per-workgroup section stamps on stderr
+    if (trace) {
+        static long long *tb = nullptr;
+        static int calls = 0;
+        const int nwg = p.nh / GP * B;
+        if (!tb) (void)hipMalloc((void **)&tb, (size_t)8192 * 8 * sizeof(long long));
+        ++calls;
+        if (tb && nwg <= 8192 && calls >= 200 && calls < 204) {        // (a few launches of a warm decode loop; run with OPUS_NO_GRAPH=1)
+            AttnDecodeParams q = p;
+            q.trace = tb;
+            hipLaunchKernelGGL((attn_decode_kernel<HD, GP>), dim3(p.nh / GP, B), dim3(256), lds, s, q);
+            (void)hipStreamSynchronize(s);
+            std::vector<long long> h((size_t)nwg * 8);
+            (void)hipMemcpy(h.data(), tb, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            long long t0 = h[0];
+            for (int i = 0; i < nwg; ++i) t0 = std::min(t0, h[8 * i]);
+            const char *nm[6] = {"start", "q / k / v staged (wave 0)", "after the staging barrier", "wave 0's key tiles done", "after the combine barrier", "end"};
+            fprintf(stderr, "[attn_decode trace] B=%d heads=%d GP=%d wgs=%d (times after the first start)\n", B, p.nh, GP, nwg);
+            for (int k = 0; k < 6; ++k) {
+                std::vector<double> v;
+                for (int i = 0; i < nwg; ++i) v.push_back((h[8 * i + k] - t0) * 0.01);
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "   %-28s min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", nm[k], v.front(), v[v.size() / 10], v[v.size() / 2],
+                        v[v.size() * 9 / 10], v.back());
+            }
+        }
     }
     OPUS_LAUNCH(KC_ATTN_DECODE, (attn_decode_kernel<HD, GP>), dim3(p.nh / GP, B), dim3(256), lds, s, p);
     return hipGetLastError();

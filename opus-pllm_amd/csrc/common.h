@@ -281,6 +281,7 @@ struct AttnDecodeParams {
     float scale;
     half_t *out;                // [B][nh hd]
     int out_tiled = 0;          // write `out` in fragment order (tiled_off) for a GemmParams::a_tiled consumer
+    long long *trace = nullptr; // tuning aid (OPUS_ATTN_TRACE): 8 wall-clock stamps per workgroup
 };
 hipError_t launch_attn_decode(const AttnDecodeParams &p, int B, int hd, hipStream_t s);
 
