@@ -32,6 +32,18 @@ namespace opus {
 
 constexpr int MAXG = 8;
 
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+// V tile in LDS: row-major [key][HD], 16-B chunk c of row r stored at c ^ vswz_d(r) - the swizzle of attn_prefill_kernel's V
+// tile: the 8 consecutive rows that the two 16-lane groups of a half wave read with one ds_read_b64_tr_b16 fall on 64 banks
+template <int HD>
+__device__ __forceinline__ int vswz_d(int row) {
+    if (HD == 128) return (row & 7) << 1;
+    if (HD == 64) return ((row >> 1) & 3) << 1;
+    if (HD == 32) return ((row >> 2) & 1) << 1;
+    return 0;
+}
+
 template <int HD, int GP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
@@ -41,13 +53,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     constexpr int DV = HD / 8;                      // 16-B slices per K / V row
     constexpr int KPN = 64 / DV;                    // key groups of the PV lanes
     constexpr int KPK = 32 / KPN;                   // keys per group and tile
-    // dynamic LDS: [sq fp16 GP x HDP][sk fp16 HDP][sv fp16 HDP][pw 4 x GP x 32 f32][stats 4 x GP x 2 f32][red 4 KPN x GP x HD f32]
+    constexpr int NO = HD / 16;                     // output dim tiles of the PV MFMAs
+    // dynamic LDS: [sq fp16 GP x HDP][sk fp16 HDP][sv fp16 HDP][stats 4 x GP x 2 f32][red 4 x GP x HD f32][vt fp16 4 x 32 x HD]
     half_t *sq = reinterpret_cast<half_t *>(smraw);
     half_t *sk = sq + GP * HDP;
     half_t *sv = sk + HDP;
-    float *pw = reinterpret_cast<float *>(sv + HDP);
-    float *stats = pw + 4 * GP * 32;
+    float *stats = reinterpret_cast<float *>(sv + HDP);
     float *red = stats + 4 * GP * 2;
+    half_t *vt = reinterpret_cast<half_t *>(red + 4 * GP * HD);
 
     // every kernel argument the staging phase needs in ONE scalar round trip: left to itself the compiler fetches them in two
     // batches (the second one just before the first vector load), i.e. two dependent misses before any data is requested
@@ -231,9 +244,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         default: stage(std::integral_constant<int, 8>{}); break;   // launch_attn_decode rejects ks > 8
     }
     const int t_first = kstart >> 5;                // first tile with a visible key
-    const int t_end = (slot + 31) >> 5;             // cached keys are slots kstart .. slot-1; the new key comes from LDS
-    const int ntiles = t_end > t_first ? t_end - t_first : 0;
-    const int new_wave = ntiles & 3;                // the wave with the fewest tiles also takes the new key
+    const int t_new = slot >> 5;                    // cached keys are slots kstart .. slot-1; the new key (slot) comes from LDS
     if (HD < HDP) {                                  // zero padding of the 32-wide MFMA k extent
         for (int i = tid; i < (GP + 1) * (HDP - HD); i += 256) {
             const int j = i / (HDP - HD), d = HD + i % (HDP - HD);
@@ -251,16 +262,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     for (int s = 0; s < KS; ++s)
         qf[s] = li < GP ? *reinterpret_cast<const h8 *>(sq + li * HDP + 32 * s + 8 * g) : h8{0, 0, 0, 0, 0, 0, 0, 0};
 
-    float m_run = -INFINITY, l_run = 0.f;            // per lane: head li, its own keys (l is summed over g at the end)
-    float acc[GP][8];
+    // per lane (li = head, g): running maximum, this lane's share of the row sum (summed over g at the end) and
+    // O^T[dim 16 n + 4 g + r][head li] = o[n][r]
+    float m_run = -INFINITY, l_run = 0.f;
+    f4 o[NO];
 #pragma unroll
-    for (int h = 0; h < GP; ++h)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
-    float *myp = pw + wave * GP * 32;
+    for (int n = 0; n < NO; ++n) o[n] = f4{0.f, 0.f, 0.f, 0.f};
+    half_t *myv = vt + wave * 32 * HD;               // this wave's V tile: row-major [32 keys][HD], 16-B chunks XOR-swizzled
 
-    // one tile of 32 keys of which [lo, hi) are visible (lo < hi); K fragments in kf, V rows in vr
+    // one tile of 32 keys of which [lo, hi) are visible (lo < hi); K fragments in kf, V rows in vr.
+    //   S^T = K q^T      lane (li = head, g): s2[a][r] = score of key 16a + 4g + r
+    //   O^T += V^T P^T   the fp16-rounded probabilities are the B operand as they stand (contraction index key(g, e) =
+    //                    16 (e / 4) + 4 g + e % 4, as in attn_prefill_kernel); V^T fragments come from the wave's row-major
+    //                    V tile in LDS through the transposing read ds_read_b64_tr_b16.  (Round 2 ran this product on the
+    //                    VALU from a probability patch in LDS: 256 FMAs + 40 LDS reads per lane and tile at GP = 4.)
     auto tile = [&](int lo, int hi) {
+        // V rows -> LDS; rows outside [lo, hi) as zeros (their probabilities are exactly 0, and 0 x anything must stay 0)
+        const bool ragged = lo > 0 || hi < 32;       // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < KPK; ++i) {
+            const int j = KPK * kp + i;
+            h8 v = vr[i];
+            if (ragged && (j < lo || j >= hi)) v = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<h8 *>(myv + j * HD + (dv ^ vswz_d<HD>(j)) * 8) = v;
+        }
         f4 s2[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -268,7 +293,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) s2[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[a][s], qf[s], s2[a], 0, 0, 0);
         }
-        // lane (li = head, g): s2[a][r] = score of key 16a + 4g + r
         float mx = -INFINITY;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -284,74 +308,73 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         const float m_new = fmaxf(m_run, mx);        // lo < hi: finite
         const float alpha = __expf(m_run - m_new);   // 0 on the first tile
         float ps = 0.f;
+        h8 pf;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f4 pv;
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // P is rounded to fp16 before the PV product, as the prefill kernel and HF (softmax .to(q.dtype))
-                const float e = __expf(s2[a][r] - m_new);   // (0 for masked keys: their V rows may hold anything finite or not,
-                ps += e;                                      //  so the product below is guarded)
-                pv[r] = (float)(half_t)e;
+                const float e = __expf(s2[a][r] - m_new);   // (0 for masked keys)
+                ps += e;
+                pf[4 * a + r] = (half_t)e;
             }
-            if (li < GP) *reinterpret_cast<f4 *>(myp + li * 32 + 16 * a + 4 * g) = pv;
-        }
         l_run = l_run * alpha + ps;
         m_run = m_new;
-        // same-wave LDS round trip (in-order LDS queue); the fences keep the compiler from reordering across it
+        // same-wave LDS round trip of the V tile (in-order LDS queue); the fences keep the compiler from reordering across it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int h = 0; h < GP; ++h) {
-            const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), h));
-            float pj[KPK];
-#pragma unroll
-            for (int i = 0; i < KPK; ++i) pj[i] = myp[h * 32 + KPK * kp + i];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float o = acc[h][e] * al;
-#pragma unroll
-                for (int i = 0; i < KPK; ++i) o += pj[i] * (float)vr[i][e];
-                acc[h][e] = o;
-            }
+        for (int n = 0; n < NO; ++n) {
+            const int r0 = 4 * g + (li >> 2), r1 = r0 + 16;
+            const int cc = 2 * n + ((li & 3) >> 1), off = (li & 1) * 4;
+            const s4v lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s4v *)(myv + r0 * HD + (cc ^ vswz_d<HD>(r0)) * 8 + off));
+            const s4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s4v *)(myv + r1 * HD + (cc ^ vswz_d<HD>(r1)) * 8 + off));
+            const s8v both = s8v{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            o[n] *= alpha;
+            o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, both), pf, o[n], 0, 0, 0);
         }
-        // the patch is rewritten by the next tile: its reads above must have retired (same wave, in order)
+        // the V tile is rewritten by the next tile: its reads above must have retired (same wave, in order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    for (int t = t_first + wave; t < t_end; t += 4) {
+    // The new key / value (fed from LDS: nothing depends on in-launch global visibility) takes its place - cache slot `slot` -
+    // in the tile that slot belongs to: no separate one-key tile on top of one wave's share (that wave was the critical path).
+    for (int t = t_first + wave; t <= t_new; t += 4) {
         if (t != wave) load_tile(t);                 // (the tile requested at entry is the right one unless the row is padded by >= 32)
-        const int lo = kstart - 32 * t, hi = slot - 32 * t;
+        const int lo = kstart - 32 * t;
+        int hi = slot - 32 * t;
+        if (t == t_new) {                            // (wave-uniform) hi = the new key's index in this tile
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const h8 nk = *reinterpret_cast<const h8 *>(sk + 32 * s + 8 * g);
+                    kf[a][s] = 16 * a + li == hi ? nk : kf[a][s];
+                }
+            const h8 nv = *reinterpret_cast<const h8 *>(sv + dv * 8);
+#pragma unroll
+            for (int i = 0; i < KPK; ++i) vr[i] = KPK * kp + i == hi ? nv : vr[i];
+            ++hi;
+        }
         tile(lo > 0 ? lo : 0, hi < 32 ? hi : 32);
     }
-    if (wave == new_wave) {                          // the new key / value: a one-key tile fed from LDS
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                kf[a][s] = (a == 0 && li == 0) ? *reinterpret_cast<const h8 *>(sk + 32 * s + 8 * g) : h8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < KPK; ++i)
-            vr[i] = (i == 0 && kp == 0) ? *reinterpret_cast<const h8 *>(sv + dv * 8) : h8{0, 0, 0, 0, 0, 0, 0, 0};
-        tile(0, 1);
-    }
-
     if (p.trace && tid == 0) p.trace[wgid * 8 + 3] = wall_clock64();       // (wave 0's key tiles done)
+
     // ---- publish (m, l) per head and the partial outputs; combine ----
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    if (g == 0 && li < GP) {
-        stats[(wave * GP + li) * 2] = m_run;
-        stats[(wave * GP + li) * 2 + 1] = l_run;
-    }
+    if (li < GP) {
+        if (g == 0) {
+            stats[(wave * GP + li) * 2] = m_run;
+            stats[(wave * GP + li) * 2 + 1] = l_run;
+        }
 #pragma unroll
-    for (int h = 0; h < GP; ++h) {
-        float *dst = red + ((int64_t)((wave * KPN + kp) * GP + h)) * HD + dv * 8;
-        *reinterpret_cast<f4 *>(dst) = f4{acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
-        *reinterpret_cast<f4 *>(dst + 4) = f4{acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
+        for (int n = 0; n < NO; ++n) *reinterpret_cast<f4 *>(red + (wave * GP + li) * HD + 16 * n + 4 * g) = o[n];
     }
     __syncthreads();
     if (p.trace && tid == 0) p.trace[wgid * 8 + 4] = wall_clock64();
@@ -365,9 +388,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         for (int w = 0; w < 4; ++w) {
             const float mw = stats[(w * GP + h) * 2];
             const float f = mw == -INFINITY ? 0.f : __expf(mw - M);
-            float s = 0.f;
-            for (int q = 0; q < KPN; ++q) s += red[((int64_t)((w * KPN + q) * GP + h)) * HD + d];
-            num += f * s;
+            num += f * red[(w * GP + h) * HD + d];
             den += f * stats[(w * GP + h) * 2 + 1];
         }
         const int kcol = (h0 + h) * HD + d;             // column of the [B, nh HD] context matrix
@@ -378,9 +399,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 
 template <int HD, int GP>
 static hipError_t launch_t(const AttnDecodeParams &p, int B, hipStream_t s) {
-    constexpr int HDP = HD < 32 ? 32 : HD, KPN = 64 / (HD / 8);
-    const size_t lds = (size_t)(GP * HDP + 2 * HDP) * sizeof(half_t) +
-                       ((size_t)4 * GP * 32 + 4 * GP * 2 + (size_t)4 * KPN * GP * HD) * sizeof(float);
+    constexpr int HDP = HD < 32 ? 32 : HD;
+    const size_t lds = (size_t)(GP * HDP + 2 * HDP) * sizeof(half_t) + ((size_t)4 * GP * 2 + (size_t)4 * GP * HD) * sizeof(float) +
+                       (size_t)4 * 32 * HD * sizeof(half_t);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void *>(&attn_decode_kernel<HD, GP>), lds);
