@@ -1129,7 +1129,55 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     if (wr == 0) __builtin_amdgcn_s_barrier();                        // every wave executes the same number of barriers
     if (p.trace && tid == 0) p.trace[blockIdx.x * 4 + 2] = wall_clock64();
 
-    if (partial) {   // raw fp32 tile [256][256] of this k-part (rows / columns beyond M / N hold clamped-row products: never read)
+    if (partial && tail_split == 2 && p.combine_cnt) {
+        // Two k-parts: combined INSIDE the launch, and the tile finished by this kernel's own epilogue.  The workgroup of the
+        // pair that finishes its half first publishes its accumulators (write-through stores, drained, then a flag); the other
+        // one waits for the flag - its partner is running, and waits for nobody - adds them to its own and runs the epilogue.
+        // a + b in fp32 is the same number whichever half arrives first: bitwise reproducible.  One slab written and read
+        // instead of two, and no pp_tail_reduce_kernel launch (29 us behind the prefill wo / down GEMMs).
+        typedef unsigned int u4p __attribute__((ext_vector_type(4)));
+        const int tt = bid - full_tiles;
+        int *cnt = p.combine_cnt + 512 + 2 * tt;                      // (gemm_stream_kernel's tickets live below 512)
+        int *word = reinterpret_cast<int *>(smem);
+        if (tid == 0) *word = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int order = *word;                                      // uniform
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ws + ((int64_t)tt << 16)), 0, 1 << 18, 0x00020000);
+        if (order == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4p, acc[i][j]), srs, ((i * 4 + j) * 512 + tid) * 16, 0, 16);   // aux 16 = sc1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed for the next launch
+            __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // the partner's accumulators: global -> LDS by DMA (no staging registers: the kernel is at its register limit), this
+        // wave's 32 KB in two halves through its 16 KB of the idle ring, then added in place
+        {
+            const char *sb = reinterpret_cast<const char *>(p.ws + ((int64_t)tt << 16));
+            char *myl = smem + wave * 16384;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(sb + ((int64_t)((h * 16 + q) * 512 + tid)) * 16), (lptr_t)(myl + q * 1024), 16, 0, 16);   // aux 16 = sc1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[(h * 16 + q) >> 2][(h * 16 + q) & 3] += *reinterpret_cast<const f4 *>(myl + q * 1024 + lane * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    } else if (partial) {   // raw fp32 tile [256][256] of this k-part (rows / columns beyond M / N hold clamped-row products: never read)
         float *slab = p.ws + (((int64_t)(bid - full_tiles) * tail_split + kpart) << 16);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1623,9 +1671,12 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
             }
         }
     }
+    // two k-parts: combined in the launch (gemm_pp_kernel); knob misc6 = 1: slabs + pp_tail_reduce_kernel as for more parts
+    const bool pair = split == 2 && p.combine_cnt && !g_knobs.misc[6];
+    if (!pair) p.combine_cnt = nullptr;
     OPUS_LAUNCH(KC_PP, kern, dim3(full + tail * split), dim3(512), 8 * 16384, s, p, bm, bn, full, split);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || split == 1) return e;
+    if (e != hipSuccess || split == 1 || pair) return e;
     if (tl_launch_ev) tl_launch_ev->aux_bytes = ((double)tail * split * 65536 * 4) + (double)tail * 65536 * (p.out_f32 ? 4 : 2);
     OPUS_LAUNCH(KC_REDUCE, (pp_tail_reduce_kernel<EPI>), dim3(tail, 8), dim3(256), 0, s, p, bm, bn, full, split);
     return hipGetLastError();

@@ -173,6 +173,16 @@ if __name__ == "__main__":
             bench_tile("dec wgu silu", 6144, 28672, 4096, 2)
         _cabi.check(lib.opus_debug_knob(model._ctx, b"misc5", 0))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pair":      # tail tiles in two k-parts: combined in the launch (0) or by pp_tail_reduce_kernel (knob misc6 = 1)
+        for rnd in range(2):
+            for off in (0, 1):
+                _cabi.check(lib.opus_debug_knob(model._ctx, b"misc6", off))
+                print(f"== misc6 = {off}")
+                bench_tile("dec wo +res", 6144, 4096, 4096, 0, True, True)
+                bench_tile("dec wd +res", 6144, 4096, 14336, 0, True, True)
+                bench_tile("dec wgu silu", 6144, 28672, 4096, 2)
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"misc6", 0))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pptrace":   # run with OPUS_PP_TRACE=1: section times of gemm_pp_kernel per shape
         bench_tile("esm qkv", 32896, 3840, 1280, 0, iters=2)
         bench_tile("esm wo +res", 32896, 1280, 1280, 0, True, True, iters=2)
