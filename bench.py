@@ -36,6 +36,11 @@ RDZV_TIMEOUT_S = 600       # every collective wait is bounded ("bound 
 _T0 = time.time()
 
 
+def _cabi_bf16() -> bool:
+    """OPUS_DTYPE=bf16 runs the same step on the bf16-operand build of the library (libopus_pllm_bf16.so)."""
+    return os.environ.get("OPUS_DTYPE", "fp16").lower() in ("bf16", "bfloat16")
+
+
 def log(msg):
     """progress on stderr (rank 0): keeps long runs visibly alive, never part of the JSON line"""
     if int(os.environ.get("RANK", "0")) == 0:
@@ -440,7 +445,7 @@ def main():
         "metric": "proteins_per_sec", "value": world * B * a.steps / dt, "unit": "proteins/s",
         "generated_tokens_per_sec": world * B * N_new * a.steps / dt,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if _cabi_bf16() else "f16", "data": "synthetic",
         "config": {"workload": f"OPUS-PLLM-{a.model} shape: batch {B}/GPU, "
                                f"{'mixed 128-1024' if mixed else a.residues}-residue proteins, 89-id prompt (+8 protein tokens = 96 "
                                f"positions), {N_new} new tokens, greedy"

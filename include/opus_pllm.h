@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 5
+#define OPUS_ABI_VERSION 6
 
 enum opus_status {
     OPUS_OK = 0,
@@ -61,6 +61,12 @@ typedef struct opus_config {
 typedef struct opus_ctx opus_ctx;
 
 int opus_abi_version(void);
+/* The 16-bit operand type of THIS build of the library: 0 = IEEE fp16 (libopus_pllm.so: the reference's unquantised dtype,
+ * model/builder.py:57 `torch_dtype=torch.float16`), 1 = bfloat16 (libopus_pllm_bf16.so, built from the same sources with
+ * -DOPUS_BF16: SURVEY 8(d) "bf16 switchable").  Wherever this header says "fp16" for a matrix, an activation or the KV cache it
+ * means this type (dtype tag OPUS_F16 = "the build's 16-bit type"); accumulation, residual stream, norms, softmax and logits
+ * are fp32 in both builds. */
+int opus_operand_dtype(void);
 const char *opus_last_error(void);
 
 /* Bytes of device memory opus_ctx_create will allocate for this config (workspace + KV cache). */

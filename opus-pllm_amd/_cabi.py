@@ -12,10 +12,19 @@ from typing import Optional
 from .config import OpusConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libopus_pllm.so")
-ABI_VERSION = 5
+# OPUS_DTYPE=bf16 (read once, before the first call) selects the bf16-operand build of the same sources (csrc/common.h,
+# -DOPUS_BF16); default: fp16, the reference's unquantised dtype (model/builder.py:57)
+BF16 = os.environ.get("OPUS_DTYPE", "fp16").lower() in ("bf16", "bfloat16")
+LIB_PATH = os.path.join(_HERE, "lib", "libopus_pllm_bf16.so" if BF16 else "libopus_pllm.so")
+ABI_VERSION = 6
 
-OPUS_F16, OPUS_F32, OPUS_I32, OPUS_I64, OPUS_U8 = 0, 1, 2, 3, 4
+OPUS_F16, OPUS_F32, OPUS_I32, OPUS_I64, OPUS_U8 = 0, 1, 2, 3, 4      # (OPUS_F16 = the build's 16-bit operand type)
+
+
+def operand_dtype():
+    """torch dtype of the library's 16-bit operands (weights, activations, KV cache)."""
+    import torch
+    return torch.bfloat16 if BF16 else torch.float16
 
 
 class OpusError(RuntimeError):
@@ -48,6 +57,7 @@ _P = C.c_void_p
 # name -> (restype, argtypes): every symbol include/opus_pllm.h declares
 SIGNATURES = {
     "opus_abi_version": (C.c_int, []),
+    "opus_operand_dtype": (C.c_int, []),
     "opus_last_error": (C.c_char_p, []),
     "opus_workspace_bytes": (C.c_int64, [C.POINTER(CConfig)]),
     "opus_ctx_create": (C.c_int, [C.POINTER(CConfig), C.c_int, C.POINTER(_P)]),
@@ -109,6 +119,8 @@ def lib() -> C.CDLL:
     v = l.opus_abi_version()
     if v != ABI_VERSION:
         raise OpusError(-101, f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    if l.opus_operand_dtype() != (1 if BF16 else 0):
+        raise OpusError(-102, f"{LIB_PATH} was not built for {'bf16' if BF16 else 'fp16'} operands")
     _lib = l
     return l
 

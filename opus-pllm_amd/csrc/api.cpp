@@ -249,6 +249,13 @@ static int check_cfg(const opus_config *g) {
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int opus_abi_version(void) { return OPUS_ABI_VERSION; }
+extern "C" int opus_operand_dtype(void) {
+#ifdef OPUS_BF16
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char *opus_last_error(void) { return g_err; }
 
 extern "C" int64_t opus_workspace_bytes(const opus_config *cfg) {

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         for (int a = 0; a < 2; ++a) {
             s2[a] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < KS; ++s) s2[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[a][s], qf[s], s2[a], 0, 0, 0);
+            for (int s = 0; s < KS; ++s) s2[a] = mfma16(kf[a][s], qf[s], s2[a]);
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
                 (__attribute__((address_space(3))) s4v *)(myv + r1 * HD + (cc ^ vswz_d<HD>(r1)) * 8 + off));
             const s8v both = s8v{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             o[n] *= alpha;
-            o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, both), pf, o[n], 0, 0, 0);
+            o[n] = mfma16(__builtin_bit_cast(h8, both), pf, o[n]);
         }
         // the V tile is rewritten by the next tile: its reads above must have retired (same wave, in order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                 for (int t = 0; t < QT; ++t) {
                     s[t][n] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) s[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[ks], qf[t][ks], s[t][n], 0, 0, 0);
+                    for (int ks = 0; ks < KS; ++ks) s[t][n] = mfma16(kf[ks], qf[t][ks], s[t][n]);
                 }
             }
             // ---- mask + online softmax: lane (li, g) owns query qw + 16 t + li, keys kt + 16 n + 4 g + r ----
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
                     const s8v both = s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     const h8 vf = __builtin_bit_cast(h8, both);
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][j], o[t][n], 0, 0, 0);
+                    for (int t = 0; t < QT; ++t) o[t][n] = mfma16(vf, pf[t][j], o[t][n]);
                 }
         }
     };

@@ -6,11 +6,30 @@
 
 namespace opus {
 
+// The 16-bit operand type of the build: IEEE fp16 (default: the reference's unquantised dtype, model/builder.py:57) or - with
+// -DOPUS_BF16, build.py's second library libopus_pllm_bf16.so - bfloat16 (SURVEY 8(d) "bf16 switchable": Llama-3 checkpoints are
+// bf16-native).  Every kernel is written against half_t / h8 and mfma16(); accumulation, residual stream, norms and softmax are
+// fp32 in both builds.
+#ifdef OPUS_BF16
+typedef __bf16 half_t;
+typedef __bf16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+#else
 typedef _Float16 half_t;
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#endif
 typedef float f4 __attribute__((ext_vector_type(4)));
+// D = A (16 x 32) B (32 x 16) + C on the matrix cores, operands in the build's 16-bit type
+__device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) {
+#ifdef OPUS_BF16
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
 
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
 // M up to which the weight-streaming skinny kernel CAN be used (LDS-staged activations, fused RMSNorm); the mid / wide

@@ -148,8 +148,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
             for (int u = 0; u < U; ++u) {
                 const int cc = phys(c + u < c1 ? c + u : c1 - 1);
                 const h8 al = xr[cc * 8], ah = xr[cc * 8 + 4];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wl[u], acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[u], acc[0], 0, 0, 0);
+                acc[0] = mfma16(al, wl[u], acc[0]);
+                acc[0] = mfma16(ah, wh[u], acc[0]);
             }
         };
         for (int c = c0; c < c1; c += 2 * U) {
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
                 for (int i = 0; i < MT; ++i) {
                     h8 al, ah;
                     conv_a(i, ar[u][i], al, ah);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wl[u], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[u], acc[i], 0, 0, 0);
+                    acc[i] = mfma16(al, wl[u], acc[i]);
+                    acc[i] = mfma16(ah, wh[u], acc[i]);
                 }
         }
         for (; c < c1; ++c) {
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
             for (int i = 0; i < MT; ++i) {
                 h8 al, ah;
                 conv_a(i, ar[i], al, ah);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wl, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[i], 0, 0, 0);
+                acc[i] = mfma16(al, wl, acc[i]);
+                acc[i] = mfma16(ah, wh, acc[i]);
             }
         }
         if (NORM) {   // row m's squares sit in the 4 lanes (li = m, g = 0..3)
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
+                    acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);   // C^T tile
         }
         if (kt + 1 < kt1) lstore(buf ^ 1);
         __syncthreads();
@@ -636,8 +636,8 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmParams p, int ksplit)
                 const int r = 16 * i + li;
                 const h8 a0 = *reinterpret_cast<const h8 *>(base + u * MP * 128 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
                 const h8 a1 = *reinterpret_cast<const h8 *>(base + u * MP * 128 + r * 128 + (((4 + g) ^ ((r >> 1) & 7)) << 4));
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], a0, acc[i], 0, 0, 0);   // C^T tile
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], a1, acc[i], 0, 0, 0);
+                acc[i] = mfma16(wl[u], a0, acc[i]);   // C^T tile
+                acc[i] = mfma16(wh[u], a1, acc[i]);
             }
     };
     w_load(wlA, whA, c0);
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_
             if (i >= i0 && i < i1) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
+                    acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);   // C^T tile
             }
     };
     const int last = KS - 1;
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                         for (int chh = 0; chh < 2; ++chh)
                             if (rhh == rh && chh == ch)
                                 acc[4 * rhh + rt][2 * chh + ct] =
-                                    __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ct][s], af[rt][s], acc[4 * rhh + rt][2 * chh + ct], 0, 0, 0);
+                                    mfma16(bf[ct][s], af[rt][s], acc[4 * rhh + rt][2 * chh + ct]);
                 }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -1977,8 +1977,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
             else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wl[u]), "+v"(wh[u]) : "n"(2 * (U - 1)));
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], fa[u8 & 1][i][0], acc[i], 0, 0, 0);   // C^T tile
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], fa[u8 & 1][i][1], acc[i], 0, 0, 0);
+                acc[i] = mfma16(wl[u], fa[u8 & 1][i][0], acc[i]);   // C^T tile
+                acc[i] = mfma16(wh[u], fa[u8 & 1][i][1], acc[i]);
             }
             const int cn = phys(c + U < c1 ? c + U : c1 - 1);        // (clamped: a few redundant loads at the very end)
             // the refill overwrites registers the MFMAs above read: in/out operands order it behind them
@@ -2009,8 +2009,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
                 for (int i = 0; i < MT; ++i) {
                     const h8 a0 = *reinterpret_cast<const h8 *>(base + u8 * CIMG + aoff[i]);
                     const h8 a1 = *reinterpret_cast<const h8 *>(base + u8 * CIMG + (aoff[i] ^ 64));
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], a0, acc[i], 0, 0, 0);   // C^T tile
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], a1, acc[i], 0, 0, 0);
+                    acc[i] = mfma16(wl[u], a0, acc[i]);   // C^T tile
+                    acc[i] = mfma16(wh[u], a1, acc[i]);
                 }
                 w_load(u, c + U);
             }

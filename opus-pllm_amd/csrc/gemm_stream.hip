@@ -119,8 +119,8 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
         for (int j = 0; j < P; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[u][j][0], __builtin_bit_cast(h8, ar[u][i][0]), acc[j][i], 0, 0, 0);   // C^T tile
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[u][j][1], __builtin_bit_cast(h8, ar[u][i][1]), acc[j][i], 0, 0, 0);
+                acc[j][i] = mfma16(wr[u][j][0], __builtin_bit_cast(h8, ar[u][i][0]), acc[j][i]);   // C^T tile
+                acc[j][i] = mfma16(wr[u][j][1], __builtin_bit_cast(h8, ar[u][i][1]), acc[j][i]);
             }
     };
     // U named sets: set u holds step s with s % U == u (static register indices)

@@ -157,18 +157,18 @@ class OpusLlamaForCausalLM:
         B = x.shape[0]
         s = self._enter()
         with torch.cuda.stream(self._stream):
-            y = torch.empty((B, self.cfg.switch_in), dtype=torch.float16, device=self.device)
+            y = torch.empty((B, self.cfg.switch_in), dtype=_cabi.operand_dtype(), device=self.device)
             _cabi.check(self._lib.opus_protein_projector(self._ctx, x.data_ptr(), B, y.data_ptr(), s))
         self._leave()
         return y
 
     def switch_projector_embedding(self, seq_embedding: torch.Tensor) -> torch.Tensor:
         """opus_arch.py:122-131: [B, switch_in] -> fp16 [B, n_prot_tokens, hidden]."""
-        y = seq_embedding.to(self.device, torch.float16).contiguous()
+        y = seq_embedding.to(self.device, _cabi.operand_dtype()).contiguous()
         B = y.shape[0]
         s = self._enter()
         with torch.cuda.stream(self._stream):
-            z = torch.empty((B, self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16, device=self.device)
+            z = torch.empty((B, self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=_cabi.operand_dtype(), device=self.device)
             _cabi.check(self._lib.opus_switch_projector(self._ctx, y.data_ptr(), B, z.data_ptr(), s))
         self._leave()
         return z
@@ -179,10 +179,10 @@ class OpusLlamaForCausalLM:
         ids = input_ids.to(self.device, torch.int64).contiguous()
         B, Tt = ids.shape
         m = None if attention_mask is None else attention_mask.to(self.device).bool().to(torch.uint8).contiguous()
-        prot = prot.to(self.device, torch.float16).contiguous()
+        prot = prot.to(self.device, _cabi.operand_dtype()).contiguous()
         s = self._enter()
         with torch.cuda.stream(self._stream):
-            emb = torch.empty((B, cfg.max_prompt, cfg.dec_dim), dtype=torch.float16, device=self.device)
+            emb = torch.empty((B, cfg.max_prompt, cfg.dec_dim), dtype=_cabi.operand_dtype(), device=self.device)
             mo = torch.empty((B, cfg.max_prompt), dtype=torch.uint8, device=self.device)
             po = torch.empty((B, cfg.max_prompt), dtype=torch.int32, device=self.device)
             T_out = C.c_int32(0)
@@ -212,7 +212,7 @@ class OpusLlamaForCausalLM:
         N, C_ = x.shape[0], self.PROJECT_CHUNK
         s = self._enter()
         with torch.cuda.stream(self._stream):
-            z = torch.empty((N, self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16, device=self.device)
+            z = torch.empty((N, self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=_cabi.operand_dtype(), device=self.device)
             zc = None
             for r0 in range(0, N, C_):
                 n = min(C_, N - r0)
@@ -221,7 +221,7 @@ class OpusLlamaForCausalLM:
                     continue
                 xc = torch.zeros((C_, x.shape[1]), dtype=torch.float32, device=self.device)
                 xc[:n] = x[r0:]
-                zc = torch.empty((C_,) + tuple(z.shape[1:]), dtype=torch.float16, device=self.device)
+                zc = torch.empty((C_,) + tuple(z.shape[1:]), dtype=_cabi.operand_dtype(), device=self.device)
                 _cabi.check(self._lib.opus_projector_forward(self._ctx, xc.data_ptr(), C_, zc.data_ptr(), None, s))
                 z[r0:] = zc[:n]
         self._leave()
@@ -294,7 +294,7 @@ class OpusLlamaForCausalLM:
                 inputs, None, attention_mask if attention_mask is not None else torch.ones_like(inputs, dtype=torch.bool),
                 None, None, seq, seq_embedding, inference_mode=True, protein_tokens=protein_tokens)
         else:
-            dummy = torch.zeros((inputs.shape[0], self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=torch.float16,
+            dummy = torch.zeros((inputs.shape[0], self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=_cabi.operand_dtype(),
                                 device=self.device)
             embeds, mask, _ = self._splice(inputs, attention_mask, dummy, True)
         return self._greedy(embeds, mask, max_new, eos, int(pad_id), sampler)
@@ -356,7 +356,7 @@ class OpusLlamaForCausalLM:
                                                        out.data_ptr(), s))
                 if rows is not None:
                     pooled[rows] = out
-            prot = torch.empty((B, cfg.n_prot_tokens, cfg.dec_dim), dtype=torch.float16, device=self.device)
+            prot = torch.empty((B, cfg.n_prot_tokens, cfg.dec_dim), dtype=_cabi.operand_dtype(), device=self.device)
             _cabi.check(self._lib.opus_projector_forward(self._ctx, pooled.data_ptr(), B, prot.data_ptr(), None, s))
         self._leave()
         emb, mask, _ = self._splice(input_ids, attention_mask, prot, True)
@@ -365,7 +365,7 @@ class OpusLlamaForCausalLM:
     # ------------------------------------------------------------------ parity taps (tests / bench)
     def prefill_logits(self, embeds: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         B, T, _ = embeds.shape
-        embeds = embeds.to(self.device, torch.float16).contiguous()
+        embeds = embeds.to(self.device, _cabi.operand_dtype()).contiguous()
         mask = mask.to(self.device).to(torch.uint8).contiguous()
         s = self._enter()
         with torch.cuda.stream(self._stream):

@@ -31,6 +31,11 @@ import numpy as np
 
 from .config import OpusConfig
 
+
+def _bf16() -> bool:
+    from . import _cabi
+    return _cabi.BF16
+
 _MASK64 = (1 << 64) - 1
 _GOLDEN = 0x9E3779B97F4A7C15
 _IH_STD = math.sqrt(4.0 * (65536.0 ** 2 - 1.0) / 12.0)   # std of the sum of four uniform 16-bit ints
@@ -69,6 +74,9 @@ def hash_normal(tseed: int, start: int, count: int, std: float, mean: float = 0.
     v = c * scale                                              # one rounding
     if mean != 0.0:
         v = v + np.float32(mean)                               # one rounding
+    if _bf16():                                                # the bf16 build's generator rounds to bfloat16 (RNE), as torch does
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(v)).to(torch.bfloat16).float().numpy()
     return v.astype(np.float16).astype(np.float32)
 
 

@@ -139,7 +139,7 @@ def _dst_rows(p: Part, device) -> torch.Tensor:
 
 def tile_weight(t: torch.Tensor) -> torch.Tensor:
     """Row-major fp16 [N,K] on the GPU -> panel-tiled copy (same nominal shape) via opus_tile_weight."""
-    assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.is_contiguous()
+    assert t.is_cuda and t.dtype == _cabi.operand_dtype() and t.dim() == 2 and t.is_contiguous()
     out = torch.empty_like(t)
     with torch.cuda.device(t.device):
         _cabi.check(_cabi.lib().opus_tile_weight(t.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1],
@@ -163,7 +163,7 @@ class DeviceWeights:
 
     # -- construction -------------------------------------------------------------------------
     def _alloc(self, f: Fused) -> torch.Tensor:
-        t = torch.empty(f.shape, dtype=torch.float16 if f.f16 else torch.float32, device=self.device)
+        t = torch.empty(f.shape, dtype=_cabi.operand_dtype() if f.f16 else torch.float32, device=self.device)
         self.tensors[f.name] = t
         return t
 
@@ -194,15 +194,15 @@ class DeviceWeights:
                     src = get(p.canon, t.dtype).reshape(p.rows, p.cols).contiguous()
                     if lora and p.canon in lora:
                         A, B, alpha, r = lora[p.canon]
-                        A = A.to(self.device, torch.float16).contiguous()
-                        B = B.to(self.device, torch.float16).contiguous()
+                        A = A.to(self.device, _cabi.operand_dtype()).contiguous()
+                        B = B.to(self.device, _cabi.operand_dtype()).contiguous()
                         _cabi.check(lib.opus_lora_merge(src.data_ptr(), A.data_ptr(), B.data_ptr(), float(alpha) / float(r),
                                                         p.rows, p.cols, int(r), torch.cuda.current_stream().cuda_stream))
                     t2[_dst_rows(p, self.device)] = src
                 if f.name in wanted:
                     unfolded[f.name] = t.float()
                 if f.fold is not None:
-                    t.copy_((t.float() * get(f.fold, torch.float32)[None, :]).half())
+                    t.copy_((t.float() * get(f.fold, torch.float32)[None, :]).to(_cabi.operand_dtype()))
                 if f.tiled:
                     self.tensors[f.name] = tile_weight(t)
             self._derive(spec, lambda name: unfolded[name], lambda canon_name: get(canon_name, torch.float32))
@@ -240,7 +240,7 @@ class DeviceWeights:
 
         def unfolded(name):          # the fused weight `name` before the fold, row-major fp32 (a temporary of at most a few MB)
             f = by_name[name]
-            tmp = torch.empty(f.shape, dtype=torch.float16, device=self.device)
+            tmp = torch.empty(f.shape, dtype=_cabi.operand_dtype(), device=self.device)
             for p in f.parts:
                 fill(tmp, True, p, False)
             return tmp.float()
@@ -272,7 +272,7 @@ class DeviceWeights:
         for name, t in self.tensors.items():
             shape = (C.c_int64 * t.dim())(*t.shape)
             _cabi.check(lib.opus_bind_weight(ctx, name.encode(), t.data_ptr(),
-                                             _cabi.OPUS_F16 if t.dtype == torch.float16 else _cabi.OPUS_F32,
+                                             _cabi.OPUS_F16 if t.dtype == _cabi.operand_dtype() else _cabi.OPUS_F32,
                                              t.dim(), shape))
         _cabi.check(lib.opus_weights_ready(ctx))
 
