@@ -36,6 +36,16 @@ def test_cabi_exports_every_declared_symbol():
     assert b"multiple of 64" in lib.opus_last_error()
 
 
+def test_bf16_build_exports_the_same_abi():
+    """libopus_pllm_bf16.so (-DOPUS_BF16) is the same ABI: every declared symbol, and it says what it was built for."""
+    path = os.path.join(os.path.dirname(_cabi.LIB_PATH), "libopus_pllm_bf16.so")
+    l = ctypes.CDLL(path)
+    for name in _cabi.SIGNATURES:
+        assert getattr(l, name) is not None
+    l.opus_abi_version.restype = l.opus_operand_dtype.restype = ctypes.c_int
+    assert l.opus_abi_version() == _cabi.ABI_VERSION and l.opus_operand_dtype() == 1
+
+
 def test_struct_layout_matches_dataclass():
     cfg = opa.vicuna_13b()
     cc = _cabi.CConfig.from_config(cfg)
