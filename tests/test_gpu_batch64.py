@@ -555,3 +555,31 @@ def test_b64_left_padded_rows_match_rows_alone(big64):
                 assert int(one[s, 0].argmax()) == int(steps[s, i].argmax()), (i, s)
     record("b64.left_padded_row_vs_alone", dict(logits=worst, decisive=decisive))
     assert worst < ROW_VS_BATCH_LOGITS and decisive >= 6, (worst, decisive)
+
+
+def test_prefill_last_layer_tail_on_last_rows_only(big64):
+    """Row D1 / D2: behind the last decoder layer's attention only each row's LAST position is ever read (lm_head), so that
+    layer's wo / gate-up / down run on B rows with the decode kernels (knob misc7 = 0, default) - against the same prefill with
+    all B T rows through the tiled GEMMs (misc7 = 1): same logits up to the kernels' accumulation order, the same KV cache
+    (every layer's K / V are written for every position either way), hence the same first decode step."""
+    from opus_pllm_amd import _cabi
+    cfg, model = big64
+    lib = _cabi.lib()
+    seqs = [synth.synth_protein(150 + 5 * i, 700 + i) for i in range(64)]
+    ids = _prompts(cfg, 64)
+    prot = model.switch_projector_embedding(model.encode_projector_embedding(model.encode_seq2embedding(seqs)))
+    emb, mask, _ = model._splice(ids, None, prot, True)
+    out = {}
+    try:
+        for all_rows in (0, 1):
+            _cabi.check(lib.opus_debug_knob(model._ctx, b"misc7", all_rows))
+            lg0 = model.prefill_logits(emb, mask)
+            lg1 = model.decode_logits(lg0.argmax(-1) if all_rows == 0 else out[0][0].argmax(-1))
+            out[all_rows] = (lg0, lg1)
+    finally:
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"misc7", 0))
+    r0, r1 = rel_l2(out[0][0], out[1][0]), rel_l2(out[0][1], out[1][1])
+    record("prefill_last_rows_only_vs_all_rows", dict(prefill=r0, decode=r1))
+    assert r0 < ROW_VS_BATCH_LOGITS and r1 < ROW_VS_BATCH_LOGITS, (r0, r1)
+    decisive = _margin(out[1][0]) > MARGIN_TAU
+    assert torch.equal(out[0][0].argmax(-1)[decisive], out[1][0].argmax(-1)[decisive])
