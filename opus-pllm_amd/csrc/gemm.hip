@@ -1639,7 +1639,12 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
         sp = sp > 8 ? 8 : sp;
         if (sp > KT / 4) sp = KT / 4;                                 // at least 4 k-tiles per part (pipeline prologue)
         while (sp > 1 && ((int64_t)R * sp << 18) > p.ws_bytes) --sp;
-        if (sp > 1) { full = T - R; split = sp; }
+        // Worth it only when the part of a tile time it saves exceeds what the k-parts cost: a tile takes ~1.5 us per k-tile +
+        // ~12 us of prologue / epilogue (OPUS_PP_TRACE), two parts exchanged inside the launch cost ~22 us, slabs + the reduce
+        // launch ~30 us.  Measured at K = 1280, 2.5 rounds (tools/bench_gemm.py pair2): wo 135 us unsplit / 151 pair / 164 reduce,
+        // QKV 291 / 295 / 300; at K = 5120: fc2 412 / 381 / 400.
+        const double t_tile = 1.5 * KT + 12.0, gain = t_tile * (1.0 - 1.0 / sp), cost = (sp == 2 && p.combine_cnt && !g_knobs.misc[6]) ? 22.0 : 30.0;
+        if (sp > 1 && gain > cost) { full = T - R; split = sp; }
     }
     const int tail = T - full;
     static const bool trace = getenv("OPUS_PP_TRACE") != nullptr;      // tuning aid: per-workgroup section times on stderr

@@ -44,7 +44,7 @@ worst16, worst32 = 0.0, 0.0
 for M, N, K, epi, f32out, resid in [(1, 4096, 4096, 0, 1, True), (3, 160, 320, 1, 0, False), (17, 96, 192, 0, 1, True), (48, 4096, 4096, 0, 1, True),
                                     (64, 6144, 4096, 0, 0, False), (64, 1024, 512, 2, 0, False), (64, 20480, 1088, 1, 0, False),
                                     (300, 512, 1280, 2, 0, False), (514, 3840, 1280, 0, 0, False), (4100, 3000, 320, 1, 0, False),
-                                    (6144, 4096, 1024, 0, 1, True), (2304, 7424, 1280, 1, 0, False)]:
+                                    (6144, 4096, 4096, 0, 1, True), (2304, 7424, 1280, 1, 0, False)]:
     g = torch.Generator().manual_seed(M * 7 + N)
     A = (torch.randn(M, K, generator=g) * 0.5).to(BF)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)

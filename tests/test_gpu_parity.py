@@ -94,6 +94,9 @@ def test_synthetic_fill_matches_numpy_twin(dev):
     # more than 256 tiles with a last round at most half full: its tiles are cut into k-parts (tail split) and combined by
     # pp_tail_reduce_kernel - every epilogue / output type, ragged M and N inside the tail tiles
     (1300, 11100, 1280, 0, 0, False), (1280, 13312, 1024, 2, 0, False), (2304, 7424, 1280, 1, 0, False), (4608, 4608, 512, 0, 1, True),
+    # 384 tiles = 1.5 rounds with a long K: the 128 tail tiles are cut in TWO k-parts, combined inside the launch (the half that
+    # arrives second adds the first one's accumulators and runs the kernel's own epilogue): fp32 + residual, GELU fp16, gate/up
+    (6144, 4096, 4096, 0, 1, True), (3072, 8192, 3072, 1, 0, False), (3072, 16384, 3072, 2, 0, False),
 ])
 def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
     """Both GEMM kernels (skinny M<=64, tile M>64), every epilogue, ragged M/N, vs fp64 on fp16 operands."""

@@ -173,6 +173,24 @@ if __name__ == "__main__":
             bench_tile("dec wgu silu", 6144, 28672, 4096, 2)
         _cabi.check(lib.opus_debug_knob(model._ctx, b"misc5", 0))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pair2":     # short-K shapes with a two-part tail: pair combine (0) vs reduce kernel (misc6 = 1); OPUS_NO_PP_TAIL=1 for no split
+        for rnd in range(2):
+            for off in (0, 1):
+                _cabi.check(lib.opus_debug_knob(model._ctx, b"misc6", off))
+                print(f"== misc6 = {off}")
+                bench_tile("esm wo +res", 32768, 1280, 1280, 0, True, True)
+                bench_tile("esm fc2 +res", 32768, 1280, 5120, 0, True, True)
+                bench_tile("esm qkv", 32768, 3840, 1280, 0)
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"misc6", 0))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rem":       # what the 128 rows beyond 128 tile rows cost the encoder GEMMs (64 x 514 = 32896 rows)
+        for rnd in range(2):
+            for M in (32896, 32768, 128):
+                bench_tile("esm qkv", M, 3840, 1280, 0)
+                bench_tile("esm wo +res", M, 1280, 1280, 0, True, True)
+                bench_tile("esm fc1 gelu", M, 5120, 1280, 1)
+                bench_tile("esm fc2 +res", M, 1280, 5120, 0, True, True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pair":      # tail tiles in two k-parts: combined in the launch (0) or by pp_tail_reduce_kernel (knob misc6 = 1)
         for rnd in range(2):
             for off in (0, 1):
