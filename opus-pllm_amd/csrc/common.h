@@ -32,6 +32,17 @@ __device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) {
 }
 
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU_GU16 = 2 };
+// first unit of k-part `part` of `parts` over `n` units (n * parts < 2^31): 32-bit, and free when there is one part - the
+// 64-bit form of this was ~100 scalar instructions in front of the first load of every weight-streaming kernel
+__device__ __forceinline__ int kpart_begin(int n, int part, int parts) {
+    return parts == 1 ? (part ? n : 0) : (int)((unsigned)(n * part) / (unsigned)parts);
+}
+// Every GemmParams field a weight-streaming kernel reads before its first load, fetched in ONE scalar batch (the compiler
+// otherwise loads the ~330-byte argument block piecemeal: up to six dependent scalar round trips before the first weight load)
+#define OPUS_ARGS_ONE_BATCH(p)                                                                                                        \
+    asm volatile("" ::"s"((p).A), "s"((p).Af), "s"((p).W), "s"((p).C), "s"((p).bias), "s"((p).residual), "s"((p).ws), "s"((p).xh_out),  \
+                 "s"((p).ssq_out), "s"((p).row_ssq), "s"((p).lda), "s"((p).ldc), "s"((p).ldr), "s"((p).M), "s"((p).N), "s"((p).K),     \
+                 "s"((p).out_f32), "s"((p).norm_eps), "s"((p).row_nblk), "s"((p).no_rot), "s"((p).c_tiled))
 // M up to which the weight-streaming skinny kernel CAN be used (LDS-staged activations, fused RMSNorm); the mid / wide
 // kernels take over above skinny_max_m().
 constexpr int SKINNY_MAX_M_CAP = 16;

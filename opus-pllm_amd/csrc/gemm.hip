@@ -69,19 +69,20 @@ __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcp
 template <int MT, int EPI, bool NORM, bool ALDS>
 __global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float red[];
+    OPUS_ARGS_ONE_BATCH(p);
     constexpr int PB = EPI == EPI_SILU_GU16 ? 2 : 1;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nwaves = blockDim.x >> 6;
-    const int wpp = nwaves / PB;                       // waves per panel
-    const int pl = wave / wpp, kpart = wave - pl * wpp;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: the k-range arithmetic below stays scalar and 32-bit -
+    const int nwaves = blockDim.x >> 6;                            //  as per-lane 64-bit divisions it was ~350 VALU instructions
+    const int wpp = nwaves / PB;                       // waves per panel     in front of the first weight load)
+    const int pl = PB == 1 ? 0 : wave / wpp, kpart = wave - pl * wpp;
     const int chunks = p.K >> 6;
     const int npanels = (p.N + 15) >> 4;   // W is stored with its rows padded to a multiple of 16
     int panel = blockIdx.x * PB + pl;
     panel = panel < npanels ? panel : npanels - 1;
-    const int c0 = (int)((int64_t)chunks * kpart / wpp);
-    const int c1 = (int)((int64_t)chunks * (kpart + 1) / wpp);
+    const int c0 = kpart_begin(chunks, kpart, wpp);
+    const int c1 = kpart_begin(chunks, kpart + 1, wpp);
     const int g = lane >> 4, li = lane & 15;
     // dynamic LDS: [red nwaves*MT*256 f32][rss nwaves*MT*16 f32][wss 16*16 f32][xs M*K f16]
     float *rss = red + nwaves * MT * 256;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p, int tiles_
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * TBM, n0 = tn * TBN;
     const int KT = p.K / TBK;
-    const int kt0 = (int)((int64_t)KT * ks / ksplit), kt1 = (int)((int64_t)KT * (ks + 1) / ksplit);
+    const int kt0 = kpart_begin(KT, ks, ksplit), kt1 = kpart_begin(KT, ks + 1, ksplit);
     const int npanels = (p.N + 15) >> 4;   // W is stored with its rows padded to a multiple of 16
 
     const int srow = tid >> 3, schunk = tid & 7;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmParams p, int ksplit)
     const bool panel_ok = panel < npanels;
     panel = panel_ok ? panel : npanels - 1;
     const int ks = blockIdx.y;
-    const int c0 = (int)((int64_t)chunks * ks / ksplit), c1 = (int)((int64_t)chunks * (ks + 1) / ksplit);
+    const int c0 = kpart_begin(chunks, ks, ksplit), c1 = kpart_begin(chunks, ks + 1, ksplit);
     const half_t *wp = p.W + ((int64_t)panel * chunks) * 1024 + lane * 8;
 
     // ---- A staging of one stage (CH chunks): NORM: float4 pieces (row = q/16, col4 = q%16 inside a chunk);
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmParams p, int tiles_
     const int m0 = tm * BM, n0 = tn * BN;
     const int KS_all = p.K / GBK, KT64 = p.K >> 6;
     const int ky = blockIdx.y;
-    const int s0 = (int)((int64_t)KS_all * ky / ksplit), s1 = (int)((int64_t)KS_all * (ky + 1) / ksplit);
+    const int s0 = kpart_begin(KS_all, ky, ksplit), s1 = kpart_begin(KS_all, ky + 1, ksplit);
     const int KS = s1 - s0;
     const int npanels = (p.N + 15) >> 4;
 
@@ -1859,6 +1860,7 @@ hipError_t launch_splitk_reduce(const GemmParams &p, int ks, hipStream_t s) {
 template <int MT, int EPI>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    OPUS_ARGS_ONE_BATCH(p);
     constexpr int MP = 16 * MT;
     constexpr int SC = MT <= 4 ? 8 : 4;                              // 64-k chunks per stage (2 stages <= 128 KB of LDS)
     constexpr int CIMG = MP * 128;                                   // bytes of one chunk image [MP][64] fp16
@@ -1874,7 +1876,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
     const bool panel_ok = panel < npanels;
     panel = panel_ok ? panel : npanels - 1;
     const int ky = blockIdx.y;
-    const int c0 = (int)((int64_t)chunks * ky / ksplit), c1 = (int)((int64_t)chunks * (ky + 1) / ksplit);
+    const int c0 = kpart_begin(chunks, ky, ksplit), c1 = kpart_begin(chunks, ky + 1, ksplit);
     const half_t *wp = p.W + ((int64_t)panel * chunks) * 1024 + lane * 8;
 
     typedef const __attribute__((address_space(1))) void *gptr_t;

@@ -48,6 +48,12 @@ __device__ __forceinline__ float gelu_erf_s(float x) {   // same arithmetic as g
 template <int MT, int P, int NT, int U, int EPI>
 __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // Every kernel argument the main path reads, fetched in ONE scalar batch: left to itself the compiler loads the 330-byte
+    // argument block piecemeal - six dependent scalar round trips before the first weight load was issued (OPUS_STREAM_TRACE's
+    // "start -> first sets" included them).
+    asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.C), "s"(p.bias), "s"(p.residual), "s"(p.ws), "s"(p.xh_out), "s"(p.ssq_out), "s"(p.combine_cnt),
+                 "s"(p.trace), "s"(p.lda), "s"(p.ldc), "s"(p.ldr), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.out_f32), "s"(p.a_tiled), "s"(p.c_tiled),
+                 "s"(p.xh_tiled), "s"(p.no_rot), "s"(ksplit));
     constexpr int NW = NT / 64;
     constexpr int TILES = P * MT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -55,7 +61,10 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
     const int g = lane >> 4, li = lane & 15;
     const int chunks = p.K >> 6;
     const int ky = blockIdx.y;
-    const int c0 = (int)((int64_t)chunks * ky / ksplit), c1 = (int)((int64_t)chunks * (ky + 1) / ksplit);
+    // (the planner's k-part counts are powers of two: a shift, not the ~200 scalar instructions of two 64-bit divisions that
+    //  stood between the kernel-argument fetch and the first weight load)
+    const int ksh = __builtin_ctz((unsigned)ksplit);
+    const int c0 = (chunks * ky) >> ksh, c1 = (chunks * (ky + 1)) >> ksh;
     const int nck = c1 - c0;
     const int nsteps = (nck + NW - 1) / NW;
     const int panel0 = blockIdx.x * P;
@@ -374,6 +383,7 @@ static hipError_t launch_stream_t(const GemmParams &p_in, const StreamPlan &pl, 
             q3(en, "end (after first start)");
         }
     }
+    if (pl.ks & (pl.ks - 1)) return hipErrorInvalidValue;               // (the kernel cuts K with a shift)
     OPUS_LAUNCH(KC_STREAM, (gemm_stream_kernel<MT, P, NT, U, EPI>), dim3(npanels / P, pl.ks), dim3(NT), lds, s, p, pl.ks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || pl.ks == 1 || p_in.slab_only || combine) return e;
