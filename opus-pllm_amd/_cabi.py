@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OPUS_DTYPE=bf16 (read once, before the first call) selects the bf16-operand build of the same sources (csrc/common.h,
 # -DOPUS_BF16); default: fp16, the reference's unquantised dtype (model/builder.py:57)
 BF16 = os.environ.get("OPUS_DTYPE", "fp16").lower() in ("bf16", "bfloat16")
-LIB_PATH = os.path.join(_HERE, "lib", "libopus_pllm_bf16.so" if BF16 else "libopus_pllm.so")
+LIB_PATH = os.environ.get("OPUS_LIB_PATH") or os.path.join(_HERE, "lib", "libopus_pllm_bf16.so" if BF16 else "libopus_pllm.so")   # (OPUS_LIB_PATH: A/B builds)
 ABI_VERSION = 6
 
 OPUS_F16, OPUS_F32, OPUS_I32, OPUS_I64, OPUS_U8 = 0, 1, 2, 3, 4      # (OPUS_F16 = the build's 16-bit operand type)

@@ -220,36 +220,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
             for (int t = 0; t < QT; ++t) {
                 // row maximum of the raw scores (the scale is positive): 4 NSUB in-lane values (v_max3 chain), then the four
                 // lane groups with two row swaps (v_permlane16_swap / v_permlane32_swap: no LDS round trip)
+                // row maximum of the raw scores (the scale is positive): the in-lane values in C++ (the compiler knows the wait
+                // states a VALU read of an MFMA result needs - an asm block reading the scores directly would not be covered by
+                // its hazard recogniser; -fno-honor-nans keeps it at 13 max instructions per 16 scores), then the four lane groups
+                // with two row swaps
+                float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+#pragma unroll
+                for (int n = 1; n < NSUB; ++n) mx = fmaxf(fmaxf(mx, fmaxf(s[t][n][0], s[t][n][1])), fmaxf(s[t][n][2], s[t][n][3]));
                 float ma, mb;
-                if constexpr (NSUB == 4) {
-                    // one asm block (the compiler pads every asm statement with s_nop): 16 in-lane values, then the rows
-                    asm volatile(
-                        "v_max3_f32 %0, %2, %3, %4\n\t"
-                        "v_max3_f32 %0, %0, %5, %6\n\t"
-                        "v_max3_f32 %0, %0, %7, %8\n\t"
-                        "v_max3_f32 %0, %0, %9, %10\n\t"
-                        "v_max3_f32 %0, %0, %11, %12\n\t"
-                        "v_max3_f32 %0, %0, %13, %14\n\t"
-                        "v_max3_f32 %0, %0, %15, %16\n\t"
-                        "v_max_f32 %0, %0, %17\n\t"
-                        "v_mov_b32 %1, %0\n\t"
-                        "s_nop 1\n\t"
-                        "v_permlane16_swap_b32 %0, %1\n\t"
-                        "v_max_f32 %0, %0, %1\n\t"
-                        "v_mov_b32 %1, %0\n\t"
-                        "s_nop 1\n\t"
-                        "v_permlane32_swap_b32 %0, %1"
-                        : "=&v"(ma), "=&v"(mb)
-                        : "v"(s[t][0][0]), "v"(s[t][0][1]), "v"(s[t][0][2]), "v"(s[t][0][3]), "v"(s[t][1][0]), "v"(s[t][1][1]),
-                          "v"(s[t][1][2]), "v"(s[t][1][3]), "v"(s[t][2][0]), "v"(s[t][2][1]), "v"(s[t][2][2]), "v"(s[t][2][3]),
-                          "v"(s[t][3][0]), "v"(s[t][3][1]), "v"(s[t][3][2]), "v"(s[t][3][3]));
-                } else {
-                    float mx = max3(s[t][0][0], s[t][0][1], s[t][0][2]);
-                    mx = NSUB > 1 ? max3(mx, s[t][0][3], s[t][1 % NSUB][0]) : fmaxf(mx, s[t][0][3]);
-                    if constexpr (NSUB > 1) mx = fmaxf(max3(mx, s[t][1 % NSUB][1], s[t][1 % NSUB][2]), s[t][1 % NSUB][3]);
-                    mx = xor16_max(mx);
-                    xor32_pair(mx, ma, mb);
-                }
+                mx = xor16_max(mx);
+                xor32_pair(mx, ma, mb);
                 const float mnew = max3(mrow[t], ma, mb);
                 const float msafe = mnew == -INFINITY ? 0.f : mnew;       // (rows with no visible key so far)
                 const float msc = msafe * sc;
