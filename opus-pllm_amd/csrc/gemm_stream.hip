@@ -286,12 +286,15 @@ static bool stream_plan(int M, int N, int K, bool slab_only, bool a_tiled, int64
     int best = 0;
     // (measured and not kept for the QKV shape: 6 panels x 4 k-parts on 4 waves - half the activation bytes per CU, twice the
     //  slabs - 14.4 vs 13.7 us at 64 rows)
-    const int cand[][2] = {{1, 1}, {3, 2}, {3, 4}, {4, 4}};            // (ties: the earlier candidate, i.e. the smaller ks)
+    // (5 panels x 4 k-parts: 320-panel outputs - the 13B decoders' hidden size 5120 - on exactly 256 workgroups; up to 3 row tiles:
+    //  the partial tiles of 8 waves x 5 panels x 4 row tiles would not fit the LDS)
+    const int cand[][2] = {{1, 1}, {3, 2}, {3, 4}, {4, 4}, {5, 4}};    // (ties: the earlier candidate, i.e. the smaller ks)
     for (auto &c : cand) {
         const int P = c[0], ks = c[1];
         if (npanels % P) continue;
         if (P == 3 && !slab_only) continue;
-        if (P == 4 && (slab_only || !a_tiled)) continue;
+        if (P >= 4 && (slab_only || !a_tiled)) continue;
+        if (P == 5 && M > 48) continue;
         const int nt = P == 1 ? 1024 : 512;
         if (chunks / ks < nt / 64) continue;              // at least one chunk per wave
         const int wgs = npanels / P * ks;
@@ -400,6 +403,14 @@ static hipError_t launch_stream_e(const GemmParams &p, const StreamPlan &pl, hip
             case 3: return launch_stream_t<3, 4, 512, 2, EPI>(p, pl, s);
             case 4: return launch_stream_t<4, 4, 512, 2, EPI>(p, pl, s);
         }
+    }
+    if (pl.P == 5) {
+        switch (mt) {
+            case 1: return launch_stream_t<1, 5, 512, 2, EPI>(p, pl, s);
+            case 2: return launch_stream_t<2, 5, 512, 2, EPI>(p, pl, s);
+            case 3: return launch_stream_t<3, 5, 512, 2, EPI>(p, pl, s);
+        }
+        return hipErrorInvalidValue;
     }
     if (pl.P == 1) {
         switch (mt) {

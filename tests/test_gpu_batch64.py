@@ -383,7 +383,9 @@ def _tile_rows(A16):
 # projection at > 16 rows: 4 panels x 4 k-parts per workgroup, slabs summed by splitk_reduce4 behind the launch
 @pytest.mark.parametrize("M,N,K,tiled", [(5, 4096, 4096, 0), (17, 4096, 4096, 0), (32, 4096, 4096, 0), (8, 4096, 14336, 0),
                                          (5, 4096, 4096, 1), (32, 4096, 4096, 1), (40, 4096, 4096, 1), (64, 4096, 4096, 1),
-                                         (17, 4096, 14336, 1), (40, 4096, 14336, 1), (64, 4096, 14336, 1)])
+                                         (17, 4096, 14336, 1), (40, 4096, 14336, 1), (64, 4096, 14336, 1),
+                                         # 320 panels (hidden size 5120, the 13B decoders): 5 panels x 4 k-parts, up to 48 rows
+                                         (32, 5120, 5120, 1), (48, 5120, 13824, 1), (24, 5120, 13824, 1)])
 def test_stream_gemm_vs_fp64(big64, M, N, K, tiled):
     """Row D3, kernel level: the one-launch narrow decode GEMM (gemm_stream_kernel: K cut over the waves of a workgroup,
     partial tiles combined through LDS in wave order) as decode_step issues wo / down - X <- X + A W^T on the fp32 residual
