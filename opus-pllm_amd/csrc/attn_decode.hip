@@ -378,21 +378,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
     __syncthreads();
     if (p.trace && tid == 0) p.trace[wgid * 8 + 4] = wall_clock64();
-    for (int i = tid; i < GP * HD; i += 256) {
-        const int h = i / HD, d = i % HD;
+    // 8 consecutive head dims per thread: one 16-B store into either output layout (a fragment-ordered row keeps 8 consecutive
+    // k together; one half per thread was 128-512 two-byte stores per workgroup)
+    for (int i = tid; i < GP * HD / 8; i += 256) {
+        const int h = i / (HD / 8), d = (i % (HD / 8)) * 8;
         float M = -INFINITY;
 #pragma unroll
         for (int w = 0; w < 4; ++w) M = fmaxf(M, stats[(w * GP + h) * 2]);
-        float num = 0.f, den = 0.f;
+        float num[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, den = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const float mw = stats[(w * GP + h) * 2];
             const float f = mw == -INFINITY ? 0.f : __expf(mw - M);
-            num += f * red[(w * GP + h) * HD + d];
+            const f4 lo = *reinterpret_cast<const f4 *>(red + (w * GP + h) * HD + d), hi = *reinterpret_cast<const f4 *>(red + (w * GP + h) * HD + d + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { num[e] += f * lo[e]; num[4 + e] += f * hi[e]; }
             den += f * stats[(w * GP + h) * 2 + 1];
         }
-        const int kcol = (h0 + h) * HD + d;             // column of the [B, nh HD] context matrix
-        p.out[p.out_tiled ? tiled_off(b, kcol, p.nh * HD) : (int64_t)b * p.nh * HD + kcol] = (half_t)(num / den);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)(num[e] / den);
+        const int kcol = (h0 + h) * HD + d;             // first column of the piece in the [B, nh HD] context matrix
+        *reinterpret_cast<h8 *>(p.out + (p.out_tiled ? tiled_off(b, kcol, p.nh * HD) : (int64_t)b * p.nh * HD + kcol)) = o;
     }
     if (p.trace && tid == 0) p.trace[wgid * 8 + 5] = wall_clock64();
 }
