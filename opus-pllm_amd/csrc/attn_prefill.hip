@@ -343,6 +343,8 @@ static hipError_t launch_hd(const AttnParams &p, hipStream_t s) {
     // 32 x 1026 x 40 x 64: 527 vs 635 us (655 TFLOP/s).  One tile per wave (104 VGPRs: 4 waves per SIMD, twice the
     // workgroups) stays ahead where the grid is small (batch 1: 12.6 vs 13.8 us) and at head_dim 128, where two tiles need
     // 240 VGPRs (batch-64 decoder prefill, 96 positions, causal: 47.8 vs 50.6 us; batch 1: 7.0 vs 8.6 us).
+    // (Not kept: the ragged last query block - T = 514 leaves 2 of 128 queries - as a second launch of the one-tile form:
+    //  167 vs 158-165 us on one box; the 19-30 % that block costs varies more between boxes than the split recovers.)
     bool one = !(HD <= 64 && (int64_t)p.B * p.heads * cdiv(p.T, 128) >= 512);
     if (g_knobs.misc[3]) one = !one;                                 // A/B aid
     return one ? launch_qt<HD, 1>(p, s) : launch_qt<HD, 2>(p, s);
