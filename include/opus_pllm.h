@@ -54,7 +54,7 @@ typedef struct opus_config {
     int32_t max_batch, max_enc_tokens, max_prompt, max_new_tokens;
     /* decoder family (model/builder.py:60-92): dec_arch 0 = Llama / Qwen2 (dec_qkv_bias: q/k/v biases),
      * 1 = OPT / Galactica with do_layer_norm_before (learned positions [dec_max_pos + 2, dim], LayerNorm, biased
-     * projections, fc1 - GELU - fc2; dec_act must be 0 = GELU; dec_rms_eps is then the LayerNorm epsilon) */
+     * projections, fc1 - activation - fc2; dec_act 0 = GELU (Galactica), 1 = ReLU (facebook/opt-*); dec_rms_eps is then the LayerNorm epsilon) */
     int32_t dec_arch, dec_qkv_bias, dec_act, dec_max_pos;
 } opus_config;
 

@@ -9,8 +9,8 @@ path runs in the hand-written HIP kernels of `csrc/` behind the C ABI declared i
 the compute entry points raise.
 """
 from .constants import IGNORE_INDEX, DEFAULT_SEQ_TOKEN_INDEX, DEFAULT_SEQ_TOKEN  # noqa: F401
-from .config import (OpusConfig, PRESETS, llama3_8b, vicuna_13b, c1_tiny, micro, micro_opt, micro_qwen,  # noqa: F401
-                     galactica_1_3b, galactica_6_7b, qwen2_7b)
+from .config import (OpusConfig, PRESETS, llama3_8b, vicuna_13b, c1_tiny, micro, micro_opt, micro_opt_relu, micro_qwen,  # noqa: F401
+                     galactica_1_3b, opt_1_3b, galactica_6_7b, qwen2_7b)
 from .mm_utils import tokenizer_seq_token, left_pad_sequence, get_model_name_from_path  # noqa: F401
 
 __all__ = ["IGNORE_INDEX", "DEFAULT_SEQ_TOKEN_INDEX", "DEFAULT_SEQ_TOKEN", "OpusConfig", "PRESETS",

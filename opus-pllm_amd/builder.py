@@ -110,9 +110,11 @@ def config_from_hf(hf_cfg: dict, esm: str = "t33_650M", proj_dim: int = 5120, sw
             raise NotImplementedError("post-LayerNorm OPT (opt-350m) is not built")
         if hf_cfg.get("word_embed_proj_dim", H) != H:
             raise NotImplementedError("OPT with project_in / project_out (word_embed_proj_dim != hidden_size) is not built")
-        if hf_cfg.get("activation_function", "relu") != "gelu":
-            raise NotImplementedError("only the GELU OPT variants (Galactica) are built")
+        act = hf_cfg.get("activation_function", "relu")
+        if act not in ("gelu", "relu"):
+            raise NotImplementedError(f"OPT activation_function {act!r} is not built (gelu: Galactica, relu: facebook/opt-*)")
         return OpusConfig(**esm2_dims(esm), proj_dim=proj_dim, switch_depth=switch_depth, has_protein_projector=has_protein_projector, dec_arch=1,
+                          dec_act=0 if act == "gelu" else 1,
                           dec_layers=hf_cfg["num_hidden_layers"], dec_dim=H, dec_heads=nh, dec_kv_heads=nh,
                           dec_head_dim=H // nh, dec_ffn=hf_cfg["ffn_dim"], dec_vocab=hf_cfg["vocab_size"], dec_rms_eps=1e-5,
                           dec_max_pos=hf_cfg.get("max_position_embeddings", 2048), **cap).validate()

@@ -46,7 +46,7 @@ class OpusConfig:
     dec_arch: int = 0                  # 0: Llama / Qwen2 (RMSNorm, rotary, SwiGLU); 1: OPT / Galactica (pre-LayerNorm,
     #                                    learned positions with offset 2, fc1-act-fc2, biases; `do_layer_norm_before`)
     dec_qkv_bias: int = 0              # arch 0: q/k/v projections carry a bias (Qwen2)
-    dec_act: int = 0                   # arch 1: 0 = erf-GELU (Galactica); ReLU OPTs are not built
+    dec_act: int = 0                   # arch 1: 0 = erf-GELU (Galactica), 1 = ReLU (facebook/opt-* with pre-LayerNorm)
     dec_max_pos: int = 2048            # arch 1: rows of the learned position table (+2 offset rows)
 
     # ---- derived ----
@@ -91,7 +91,7 @@ class OpusConfig:
         req(self.dec_arch in (0, 1), "dec_arch: 0 (Llama/Qwen2) or 1 (OPT/Galactica)")
         if self.dec_arch == 1:
             req(self.dec_heads == self.dec_kv_heads, "OPT attention is multi-head (dec_kv_heads == dec_heads)")
-            req(self.dec_act == 0, "only the GELU OPT variants (Galactica) are built")
+            req(self.dec_act in (0, 1), "OPT activation: 0 = GELU (Galactica) or 1 = ReLU (facebook/opt-*)")
             req(self.max_prompt + self.max_new_tokens <= self.dec_max_pos, "context exceeds the learned position table")
         return self
 
@@ -160,6 +160,12 @@ def galactica_1_3b(**kw) -> OpusConfig:
     return OpusConfig(**{**esm2_dims("t33_650M"), **base, **kw}).validate()
 
 
+def opt_1_3b(**kw) -> OpusConfig:
+    """facebook/opt-1.3b decoder shape (language_model/opus_opt.py wraps any OPTForCausalLM): as galactica_1_3b with the ReLU
+    feed-forward and OPT's 50272-entry vocabulary."""
+    return galactica_1_3b(dec_act=1, dec_vocab=50272, **kw)
+
+
 def galactica_6_7b(**kw) -> OpusConfig:
     """OPUS-PLLM-Galactica-6.7B shape: 32 x 4096, 32 heads of 128."""
     base = dict(dec_arch=1, dec_layers=32, dec_dim=4096, dec_heads=32, dec_kv_heads=32, dec_head_dim=128, dec_ffn=16384,
@@ -179,11 +185,16 @@ def micro_opt(**kw) -> OpusConfig:
     return micro(dec_arch=1, dec_kv_heads=4, dec_max_pos=96, **kw)
 
 
+def micro_opt_relu(**kw) -> OpusConfig:
+    """micro_opt with the ReLU feed-forward of the facebook/opt-* checkpoints (golden fixture of row N4)."""
+    return micro_opt(dec_act=1, **kw)
+
+
 def micro_qwen(**kw) -> OpusConfig:
     """micro with q/k/v biases (golden fixtures of row N4)."""
     return micro(dec_qkv_bias=1, **kw)
 
 
 PRESETS = {"llama3_8b": llama3_8b, "vicuna_13b": vicuna_13b, "c1_tiny": c1_tiny, "micro": micro,
-           "galactica_1_3b": galactica_1_3b, "galactica_6_7b": galactica_6_7b, "qwen2_7b": qwen2_7b,
-           "micro_opt": micro_opt, "micro_qwen": micro_qwen}
+           "galactica_1_3b": galactica_1_3b, "opt_1_3b": opt_1_3b, "galactica_6_7b": galactica_6_7b, "qwen2_7b": qwen2_7b,
+           "micro_opt": micro_opt, "micro_opt_relu": micro_opt_relu, "micro_qwen": micro_qwen}

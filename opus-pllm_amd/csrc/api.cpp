@@ -240,7 +240,8 @@ static int check_cfg(const opus_config *g) {
     if (g->dec_arch != 0 && g->dec_arch != 1) return fail(OPUS_EBADARG, "dec_arch must be 0 (Llama/Qwen2) or 1 (OPT/Galactica)");
     if (g->dec_arch == 1) {
         if (g->dec_heads != g->dec_kv_heads) return fail(OPUS_ESHAPE, "OPT attention is multi-head: dec_kv_heads == dec_heads");
-        if (g->dec_act != 0) return fail(OPUS_EUNSUPPORTED, "only the GELU OPT variants (Galactica) are built");
+        if (g->dec_act != 0 && g->dec_act != 1) return fail(OPUS_EUNSUPPORTED, "OPT activation: 0 = GELU (Galactica) or 1 = ReLU (facebook/opt-*)");
+        if (g->dec_ffn & 7) return fail(OPUS_ESHAPE, "dec_ffn must be a multiple of 8");
         if (g->max_prompt + g->max_new_tokens > g->dec_max_pos)
             return fail(OPUS_ESHAPE, "max_prompt + max_new_tokens exceeds the learned position table (dec_max_pos=%d)", g->dec_max_pos);
     }
@@ -850,7 +851,12 @@ static int opt_layer(opus_ctx *c, hipStream_t s, const DecLayer &L, int l, float
     }
     OPC(gemm(c, s, c->d_ctx, QD, L.wo, M, H, QD, L.bo, EPI_NONE, x, x, H, 1));
     KL(KC_NORM, 6.0 * M * H, launch_layernorm(x, L.ln2w, L.ln2b, g.dec_rms_eps, M, H, xn, nullptr, s));
-    OPC(gemm(c, s, xn, H, L.w1, M, F, H, L.b1, EPI_GELU, nullptr, c->d_act, F, 0));
+    if (g.dec_act == 0) {
+        OPC(gemm(c, s, xn, H, L.w1, M, F, H, L.b1, EPI_GELU, nullptr, c->d_act, F, 0));
+    } else {      // ReLU (facebook/opt-*): on the stored fp16 projection, as HF applies it to fc1's fp16 output
+        OPC(gemm(c, s, xn, H, L.w1, M, F, H, L.b1, EPI_NONE, nullptr, c->d_act, F, 0));
+        KL(KC_OTHER, 4.0 * M * F, launch_relu_h(c->d_act, (int64_t)M * F, s));
+    }
     OPC(gemm(c, s, c->d_act, F, L.w2, M, H, F, L.b2, EPI_NONE, x, x, H, 1));
     return OPUS_OK;
 }

@@ -268,6 +268,7 @@ hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int
 hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, const int32_t *step, int t0, int B, int Tq,
                           int H, int max_idx, hipStream_t s);
 hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s);
+hipError_t launch_relu_h(half_t *x, int64_t n, hipStream_t s);
 hipError_t launch_fill_synth(void *dst, int dtype, int64_t rows, int64_t cols, uint64_t seed, float std,
                              float mean, int64_t rb, int64_t rs, int64_t ro, int tiled, uint64_t fold_seed,
                              float fold_std, float fold_mean, hipStream_t s);

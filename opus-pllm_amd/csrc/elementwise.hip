@@ -218,6 +218,22 @@ hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int
     return hipGetLastError();
 }
 
+// x <- max(x, 0) in place on fp16 activations (row N4: the ReLU feed-forward of the OPT decoders other than Galactica,
+// modeling_opt.py ACT2FN["relu"] between fc1 and fc2); 8 halves per thread
+__global__ __launch_bounds__(256) void relu_h_kernel(half_t *__restrict__ x, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    h8 v = reinterpret_cast<h8 *>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] > (half_t)0.f ? v[e] : (half_t)0.f;
+    reinterpret_cast<h8 *>(x)[i] = v;
+}
+hipError_t launch_relu_h(half_t *x, int64_t n, hipStream_t s) {
+    if (n & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(relu_h_kernel, dim3(cdiv(n >> 3, 256)), dim3(256), 0, s, x, n >> 3);
+    return hipGetLastError();
+}
+
 // out[b,:] = x[b, T-1, :]   (lm_head is applied to the last position only; row D2)
 __global__ __launch_bounds__(256) void take_last_kernel(const float *__restrict__ x, int T, int H, float *__restrict__ out) {
     const int b = blockIdx.x;

@@ -97,9 +97,9 @@ def test_capacity_errors(big):
         model.generate(torch.cat([ids, ids], dim=1), seqs * 2, max_new_tokens=4)   # 2 x 96 positions > max_prompt
 
 
-@pytest.mark.parametrize("preset", ["galactica_1_3b", "qwen2_7b"])
+@pytest.mark.parametrize("preset", ["galactica_1_3b", "opt_1_3b", "qwen2_7b"])
 def test_other_decoder_families_at_full_size(preset):
-    """Row N4 at the released shapes (OPT-architecture Galactica-1.3B; Qwen2.5-7B with q/k/v biases): KV-cache
+    """Row N4 at the released shapes (OPT-architecture Galactica-1.3B, ReLU OPT-1.3B; Qwen2.5-7B with q/k/v biases): KV-cache
     consistency (decode step == prefill of the longer prompt), determinism under graph replay, left-pad invariance."""
     from opus_pllm_amd.model import OpusLlamaForCausalLM
     from opus_pllm_amd.weights import DeviceWeights

@@ -30,7 +30,7 @@ MARGIN_TAU = 0.05
 # 0.0745 and 0.0957), the OPT / Qwen2 micro fixtures have 28 of 36 ids before their rows' first near-tie.
 C1_IDS_FRACTION = 1.0
 MIDSIZE_IDS_FRACTION = 1.0
-FAMILY_IDS_FRACTION = {"generate_micro_opt": 28 / 36, "generate_micro_qwen": 28 / 36}
+FAMILY_IDS_FRACTION = {"generate_micro_opt": 28 / 36, "generate_micro_opt_relu": 18 / 36, "generate_micro_qwen": 28 / 36}
 
 
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -638,10 +638,11 @@ def test_midsize_path_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------------ N4: decoder families
-@pytest.mark.parametrize("tag,preset", [("generate_micro_opt", "micro_opt"), ("generate_micro_qwen", "micro_qwen")])
+@pytest.mark.parametrize("tag,preset", [("generate_micro_opt", "micro_opt"), ("generate_micro_opt_relu", "micro_opt_relu"),
+                                        ("generate_micro_qwen", "micro_qwen")])
 @pytest.mark.parametrize("on_gpu_fill", [False, True])
 def test_decoder_family_golden(dev, gold, tag, preset, on_gpu_fill):
-    """OPT / Galactica (learned positions, LayerNorm, biases, fc1-GELU-fc2) and Qwen2 (q/k/v biases) decoders against
+    """OPT (learned positions, LayerNorm, biases, fc1 - GELU (Galactica) or ReLU (facebook/opt-*) - fc2) and Qwen2 (q/k/v biases) decoders against
     the transformers goldens: prefill + 4 teacher-forced step logits, greedy ids, hipGraph replay; weights both from
     the canonical host tensors and from the on-device synthetic fill."""
     cfg = opa.PRESETS[preset]()

@@ -109,11 +109,19 @@ def test_missing_artefacts_fail_without_network(tmp_path, monkeypatch):
         builder._esm2_ckpt_path()
     with pytest.raises(NotImplementedError):                # a family the reference does not dispatch either (builder.py:96)
         builder.load_pretrained_model("/models/mistral-7b", None, "mistral", device="cuda:0")
-    with pytest.raises(NotImplementedError):                # post-LayerNorm / ReLU / projected-embedding OPT variants
+    with pytest.raises(NotImplementedError):                # post-LayerNorm / projected-embedding OPT (opt-350m)
         builder.config_from_hf(dict(model_type="opt", hidden_size=1024, num_attention_heads=16, do_layer_norm_before=False))
     with pytest.raises(NotImplementedError):
-        builder.config_from_hf(dict(model_type="opt", hidden_size=2048, num_attention_heads=32, activation_function="relu",
+        builder.config_from_hf(dict(model_type="opt", hidden_size=1024, num_attention_heads=16, word_embed_proj_dim=512))
+    with pytest.raises(NotImplementedError):                # an activation neither OPT release uses
+        builder.config_from_hf(dict(model_type="opt", hidden_size=2048, num_attention_heads=32, activation_function="silu",
                                     ffn_dim=8192, num_hidden_layers=2, vocab_size=100))
+    # the ReLU feed-forward of facebook/opt-* (HF's default for model_type "opt") and Galactica's GELU are both dispatched
+    relu = builder.config_from_hf(dict(model_type="opt", hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=2,
+                                       vocab_size=100))
+    gelu = builder.config_from_hf(dict(model_type="opt", hidden_size=2048, num_attention_heads=32, activation_function="gelu",
+                                       ffn_dim=8192, num_hidden_layers=2, vocab_size=100))
+    assert (relu.dec_arch, relu.dec_act, gelu.dec_act) == (1, 1, 0)
 
 
 @pytest.mark.gpu

@@ -151,7 +151,8 @@ def test_sampling_distribution_restates_hf_warpers():
         assert torch.allclose(oracle.sampling_distribution(logits, t, p), hf, atol=1e-7)
 
 
-@pytest.mark.parametrize("tag,preset", [("generate_micro_opt", "micro_opt"), ("generate_micro_qwen", "micro_qwen")])
+@pytest.mark.parametrize("tag,preset", [("generate_micro_opt", "micro_opt"), ("generate_micro_opt_relu", "micro_opt_relu"),
+                                        ("generate_micro_qwen", "micro_qwen")])
 def test_decoder_family_golden(gold, tag, preset):
     """Row N4: the OPT / Galactica and Qwen2 restatements against the local transformers models (prefill + 4
     teacher-forced steps, and the greedy ids of generate(inputs_embeds=...)) on the spliced inputs of generate_micro."""

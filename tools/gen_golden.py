@@ -406,7 +406,7 @@ def gold_decoder_family(tag, cfg, w):
     if cfg.dec_arch == 1:
         hc = OPTConfig(vocab_size=cfg.dec_vocab, hidden_size=cfg.dec_dim, ffn_dim=cfg.dec_ffn, num_hidden_layers=cfg.dec_layers,
                        num_attention_heads=cfg.dec_heads, max_position_embeddings=cfg.dec_max_pos,
-                       word_embed_proj_dim=cfg.dec_dim, do_layer_norm_before=True, activation_function="gelu",
+                       word_embed_proj_dim=cfg.dec_dim, do_layer_norm_before=True, activation_function="gelu" if cfg.dec_act == 0 else "relu",
                        enable_bias=True, layer_norm_elementwise_affine=True, dropout=0.0, tie_word_embeddings=False,
                        pad_token_id=None, bos_token_id=1, eos_token_id=None)
         hc._attn_implementation = "eager"
@@ -510,7 +510,8 @@ def main():
     print("projector variants"); gold_projector_variants()
     print("splice"); gold_splice(cfg, w, model)
     print("llama + generate (micro)"); gold_llama_and_generate(cfg, w, model, hf)
-    for tag, fam in (("generate_micro_opt", opa.micro_opt()), ("generate_micro_qwen", opa.micro_qwen())):
+    for tag, fam in (("generate_micro_opt", opa.micro_opt()), ("generate_micro_opt_relu", opa.micro_opt_relu()),
+                     ("generate_micro_qwen", opa.micro_qwen())):
         print(tag); gold_decoder_family(tag, fam, synth.canonical_weights(fam, seed=0))
     print("C1 chain")
     c1 = opa.c1_tiny()
