@@ -132,3 +132,26 @@ def test_other_decoder_families_at_full_size(preset):
     finally:
         del model
         torch.cuda.empty_cache()
+
+
+def test_two_contexts_in_flight_share_weights_and_agree(big):
+    """`model.new_context()`: a second context on the same weights; two host threads drive one batch each at the same time
+    (eval_ddp.py --inflight 2, bench.py `two_in_flight`) and both return the ids a single context returns."""
+    import threading
+    cfg, model = big
+    other = model.new_context()
+    assert other.weights is model.weights
+    seqs, ids = _inputs(cfg, 4)
+    ref = model.generate(ids, seqs, max_new_tokens=12, pad_token_id=0).cpu()
+    outs = {}
+
+    def work(k, m):
+        torch.cuda.set_device(m.device)
+        for _ in range(3):
+            outs[k] = m.generate(ids, seqs, max_new_tokens=12, pad_token_id=0).cpu()
+    th = [threading.Thread(target=work, args=(k, m)) for k, m in enumerate((model, other))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref)
+    del other
+    torch.cuda.empty_cache()

@@ -266,6 +266,13 @@ def test_two_stage_eval_loop_projects_the_shard_once(tmp_path):
     assert one.shape == (11, 8) and torch.equal(one, two)
     assert n_proj == 3 and n_enc == 0, (n_proj, n_enc)
     assert ddp.prompt_capacity(tok, items, "", model.cfg.n_prot_tokens) <= 64
+    # --inflight 2: two contexts on the same weights take the batches round-robin from two host threads; results come back in
+    # input order and are the same ids (the logits dump too)
+    lg1, lg2 = [], []
+    a = ddp.annotate(model, tok, items, "", 4, 8, logits_out=lg1)
+    b = ddp.annotate(model, tok, items, "", 4, 8, logits_out=lg2, inflight=2)
+    assert torch.equal(a, one) and torch.equal(b, one)
+    assert len(lg1) == len(lg2) == 3 and all(torch.equal(x, y) for x, y in zip(lg1, lg2))
 
 
 @pytest.mark.gpu
