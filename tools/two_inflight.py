@@ -25,7 +25,9 @@ for i in range(n):
 torch.cuda.synchronize()
 seq_ms = (time.time() - t0) / n * 1e3
 bad = [0] * NCTX
+DELAY = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0      # seconds between the starts of consecutive contexts
 def work(k, m):
+    time.sleep(k * DELAY)
     for i in range(m):
         out = models[k].generate(ids, seqs, max_new_tokens=32, pad_token_id=0).cpu()
         bad[k] += int(not torch.equal(out, ref))
@@ -35,4 +37,4 @@ th = [threading.Thread(target=work, args=(k, n // NCTX)) for k in range(NCTX)]
 torch.cuda.synchronize()
 par_ms = (time.time() - t0) / (NCTX * (n // NCTX)) * 1e3
 print(f"one context, back to back: {seq_ms:.1f} ms per batch = {B / seq_ms * 1e3:.1f} proteins/s")
-print(f"{NCTX} contexts in flight     : {par_ms:.1f} ms per batch = {B / par_ms * 1e3:.1f} proteins/s  (differing outputs: {sum(bad)})")
+print(f"{NCTX} contexts in flight (start offset {DELAY * 1e3:.0f} ms): {par_ms:.1f} ms per batch = {B / par_ms * 1e3:.1f} proteins/s  (differing outputs: {sum(bad)})")
