@@ -21,9 +21,9 @@ pmc_pair() {   # $1 = tag, rest = bench.py arguments of the step
   rm -rf $OUT/pmc_rd_$t $OUT/pmc_wr_$t $OUT/pmc_rd_$t.log $OUT/pmc_wr_$t.log
 }
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log && tail -c 300 $OUT/bench.json &&
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o main --output-format csv -- python3 bench.py --no-cpu-baseline --no-roofline > $OUT/stats.log 2>&1 &&
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o main --output-format csv -- python3 bench.py --no-cpu-baseline --no-roofline --no-inflight > $OUT/stats.log 2>&1 &&
 keep_stats $OUT/stats $OUT/kernel_stats.csv &&
-rocprofv3 --kernel-trace -d $OUT/shapes -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-c2 > $OUT/shapes.log 2>&1 &&
+rocprofv3 --kernel-trace -d $OUT/shapes -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-c2 --no-inflight > $OUT/shapes.log 2>&1 &&
 python3 tools/prof_shapes.py $OUT/shapes 0.5 > $OUT/kernel_shapes.txt && rm -rf $OUT/shapes &&
 pmc_pair b64 && pmc_pair b1 --batch 1 &&
 python3 bench.py --mixed-lengths --steps 5 --warmup 2 --no-cpu-baseline --no-c2 > $OUT/bench_c3.json 2> $OUT/bench_c3.log &&
