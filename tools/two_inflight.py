@@ -14,6 +14,9 @@ cfg = opa.llama3_8b(max_batch=B, max_enc_tokens=514, max_prompt=104, max_new_tok
 w = DeviceWeights.synthetic(cfg, 0, dev)
 NCTX = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 models = [OpusLlamaForCausalLM(cfg, w, dev) for _ in range(NCTX)]
+if os.environ.get("PRIO"):                    # experiment: context 0 on a high-priority stream, the others on normal ones
+    models[0]._stream = torch.cuda.Stream(dev, priority=-1)
+    print("stream priorities:", [m._stream.priority for m in models])
 seqs = [synth.synth_protein(512, i) for i in range(B)]
 ids = torch.tensor([synth.synth_prompt_ids(cfg.dec_vocab, i, n_text=89) for i in range(B)])
 ref = models[0].generate(ids, seqs, max_new_tokens=32, pad_token_id=0).cpu()
