@@ -189,8 +189,8 @@ def timed(work, a, world, rank, dev, dist, cdev, steps, warmup):
 def two_in_flight(model, cfg, a, rank, lengths, dev, steps, warmup):
     """The same K steps of the same workload with TWO batches in flight on the GPU: a second context that shares the model's
     weights (model.new_context(): own workspace, KV cache, decode graph and stream) and one host thread per context, each
-    running K / 2 steps.  Proteins are independent, so one batch's HBM-bound decode steps overlap the other's MFMA-bound
-    encoder / prefill and fill its launch gaps.  Reported beside the sequential headline, not instead of it."""
+    running K / 2 steps.  Proteins are independent, so one batch's kernels stream through the other's launch gaps, ramps and
+    drains (mostly in the decode steps).  Reported beside the sequential headline, not instead of it."""
     import threading
     import torch
     ctxs = [model, model.new_context()]

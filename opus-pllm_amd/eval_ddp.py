@@ -172,8 +172,8 @@ if __name__ == "__main__":
                    help="opt-in: finish a row once it has generated the ids of '###' (the reference decodes on to max_new_tokens "
                         "and cuts the text there afterwards: same text, less decoding)")
     p.add_argument("--inflight", type=int, default=2,
-                   help="batches in flight per GPU (contexts sharing the weights, one host thread each): 2 overlaps one batch's "
-                        "HBM-bound decode with the other's encoder / prefill (+10 %% throughput at batch 64; same ids)")
+                   help="batches in flight per GPU (contexts sharing the weights, one host thread each): with 2, one batch's kernels "
+                        "fill the other's launch gaps and ramps (+10 %% throughput at batch 64; same ids)")
     p.add_argument("--dump_logits", type=str, default=None,
                    help="parity dump: save the fp32 last-step logits of every item ([n, V], input order) to this .pt file")
     eval_model(p.parse_args())

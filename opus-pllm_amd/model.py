@@ -77,8 +77,8 @@ class OpusLlamaForCausalLM:
     def new_context(self) -> "OpusLlamaForCausalLM":
         """A second context on the same device that SHARES this model's weights (read-only) and owns its workspace, KV cache,
         decode graph and stream: two batches can then be in flight on one GPU (two host threads, one per context) - proteins are
-        independent, so one batch's HBM-bound decode steps run beside the other's MFMA-bound encoder / prefill and fill its launch
-        gaps (`eval_ddp.py --inflight 2`, `bench.py`'s `two_in_flight`: +10 % throughput at batch 64; same ids as one context)."""
+        independent, so one batch's kernels stream through the other's launch gaps, ramps and drains - mostly in the decode steps
+        (`eval_ddp.py --inflight 2`, `bench.py`'s `two_in_flight`: +10 % throughput at batch 64; same ids as one context)."""
         g = self.generation_config
         return OpusLlamaForCausalLM(self.cfg, self.weights, self.device, eos_token_id=list(g.eos_token_id), pad_token_id=g.pad_token_id)
 
