@@ -16,8 +16,14 @@
  *   - All work is ordered on the caller's hipStream_t (passed as void*; NULL = default stream).
  *     No hidden device synchronisation, except where a function returns a HOST scalar that depends
  *     on device data (documented per function: it synchronises the given stream once).
- *   - A context is bound to one device and is not thread-safe: one per process, as the reference's
- *     one-process-per-GPU model (model/builder.py:41).
+ *   - A context is bound to one device and is not thread-safe: one host thread drives a context at a time.  A process may
+ *     hold several contexts on the same device that BIND THE SAME weight pointers (read-only; each context owns its workspace,
+ *     KV cache, decode graph and hand-off words): two batches in flight per GPU (`model.new_context()`, one host thread and one
+ *     stream per context).  One process per GPU as in the reference (model/builder.py:41).
+ *   - Kernels that combine split-K parts INSIDE one launch wait only for workgroups that are already running, with a bounded
+ *     wait; a wait that runs out (ticket words poisoned by an aborted launch) sets a device error word instead of hanging, which
+ *     the next call that synchronises (opus_generate_*, opus_check_error) returns as OPUS_EHIP.  The words are re-zeroed at
+ *     the head of every encode / projector / prefill / decode step.
  */
 #ifndef OPUS_PLLM_H
 #define OPUS_PLLM_H
@@ -28,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 6
+#define OPUS_ABI_VERSION 7
 
 enum opus_status {
     OPUS_OK = 0,
@@ -191,7 +197,8 @@ int opus_debug_gemm_slabs(opus_ctx *ctx, const void *d_A, const void *d_W, float
 /* Process-wide tuning knob of the benchmarks / parity tests (no reference counterpart): "no_stream" = 1 routes the narrow
  * GEMMs of the batched decode step through the round-2 split-K kernels instead of gemm_stream_kernel; "pp_gm" = tile rows
  * per rasterisation group of the big tiled GEMM; "debug_a_tiled" = 1: opus_debug_gemm takes A in fragment order; "no_ln_fusion" = 1: stand-alone normalisation kernels
- * instead of the norms fused around the big tiled GEMM; "misc0".."misc7" scratch.  ctx (may be NULL) drops its captured decode graph. */
+ * instead of the norms fused around the big tiled GEMM; "poison_handoff" = 1 (needs ctx): leaves the hand-off words as an
+ * aborted launch would (test aid); "misc0".."misc7" scratch.  ctx (may be NULL) drops its captured decode graph. */
 int opus_debug_knob(opus_ctx *ctx, const char *name, int32_t value);
 /* The row-scale RMSNorm fusion as the decoder issues it (api.cpp prefill / decode_step): X <- X + A W1^T through a GEMM
  * (gemm_stream_kernel at 5..64 rows, else a split-K GEMM) whose epilogue / reduce also writes fp16(X) and per-block sums of squares, then C = epi(rmsnorm(X) W2^T) with
@@ -209,6 +216,11 @@ int opus_debug_gemm_rope(opus_ctx *ctx, const void *d_A, const void *d_W, const 
 int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const void *d_V, void *d_O,
                          const int32_t *d_kstart, const int32_t *d_kend, int32_t B, int32_t T, int32_t heads,
                          int32_t group, int32_t head_dim, int32_t causal, float scale, void *stream);
+
+/* Synchronises `stream` and returns OPUS_EHIP if an in-launch split-K hand-off of this context gave up waiting since the last
+ * check (see Conventions; the results of the calls in between are invalid), OPUS_OK otherwise.  opus_generate_* make the same
+ * check before they return.  No reference counterpart (torch raises asynchronously on device-side faults). */
+int opus_check_error(opus_ctx *ctx, void *stream);
 
 /* fp32 logits [B, dec_vocab] of the most recent prefill / decode step (device copy on `stream`): the payload of the
  * optional logits all-gather of SURVEY 8e (ids are what eval/run_opus_ddp.py:138 gathers). */

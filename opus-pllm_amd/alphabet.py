@@ -22,6 +22,30 @@ CLS_IDX, PAD_IDX, EOS_IDX, UNK_IDX, MASK_IDX = 0, 1, 2, 3, 32
 _SPECIALS = [t for t in ALL_TOKS if len(t) > 1]
 
 
+# Byte table of the fast path: every single-character symbol -> its id, ASCII whitespace -> -1 (dropped), anything else -> -2
+# (KeyError, as fair_esm).  The ASCII whitespace set is what str.isspace() accepts below 128.
+_LUT = np.full(256, -2, dtype=np.int32)
+for _t, _i in TOK_TO_IDX.items():
+    if len(_t) == 1:
+        _LUT[ord(_t)] = _i
+for _c in "\t\n\v\f\r \x1c\x1d\x1e\x1f":
+    _LUT[ord(_c)] = -1
+
+
+def encode_array(seq: str) -> np.ndarray:
+    """Token ids of one sequence as int32.  Plain residue strings (ASCII, no "<...>" symbol: every protein of a dataset) go
+    through one table look-up over the bytes; anything else takes the per-character walk of `encode` (same rules)."""
+    if seq.isascii() and "<" not in seq:
+        ids = _LUT[np.frombuffer(seq.encode("ascii"), dtype=np.uint8)]
+        if ids.size and ids.min() < 0:
+            bad = np.flatnonzero(ids == -2)
+            if bad.size:
+                raise KeyError(seq[int(bad[0])])
+            ids = ids[ids >= 0]
+        return ids
+    return np.asarray(encode(seq), dtype=np.int32)
+
+
 def encode(seq: str) -> List[int]:
     ids: List[int] = []
     i, n = 0, len(seq)
@@ -46,7 +70,7 @@ def encode(seq: str) -> List[int]:
 
 def batch_convert(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     """-> (tokens int32 [B, Lmax+2], lens int32 [B]) ; lens counts <cls> and <eos> (modelling.py:45)."""
-    enc = [encode(s) for s in seqs]
+    enc = [encode_array(s) for s in seqs]
     width = max((len(e) for e in enc), default=0) + 2
     toks = np.full((len(enc), width), PAD_IDX, dtype=np.int32)
     lens = np.zeros((len(enc),), dtype=np.int32)

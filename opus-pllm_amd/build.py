@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import concurrent.futures as cf
 import os
+import re
 import subprocess
 import sys
 
@@ -30,6 +31,37 @@ EXTRA = {"attn_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-na
          "attn_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+# Kernels that must not touch scratch memory (a spilled register in a kernel at its register ceiling is the first sign that
+# one more fusion will not fit): checked from the compiler's own resource remarks on every build, a hard failure.
+NO_SCRATCH = ("gemm_pp_kernel", "gemm_stream_kernel", "gemm_wide_kernel", "gemm_skinny_kernel", "attn_prefill_kernel",
+              "attn_decode_kernel", "beam_")
+RU_FLAG = "-Rpass-analysis=kernel-resource-usage"
+
+
+def resource_usage(text: str) -> dict:
+    """{mangled kernel name: {field: value}} from hipcc's -Rpass-analysis=kernel-resource-usage remarks."""
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([\w \[\]/]+?): (-?\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def check_resources(ru_file: str) -> None:
+    bad = []
+    for name, f in resource_usage(open(ru_file).read()).items():
+        if any(k in name for k in NO_SCRATCH) and (f.get("ScratchSize [bytes/lane]", 0) or f.get("VGPRs Spill", 0) or f.get("SGPRs Spill", 0)):
+            bad.append(f"{name}: VGPRs {f.get('VGPRs')}, scratch {f.get('ScratchSize [bytes/lane]')} B/lane, "
+                       f"spilled VGPRs {f.get('VGPRs Spill')}, spilled SGPRs {f.get('SGPRs Spill')}")
+    if bad:
+        raise RuntimeError(f"{os.path.basename(ru_file)}: hot kernels must not spill:\n  " + "\n  ".join(bad))
+
+
 def _deps_mtime() -> float:
     hdrs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "opus_pllm.h"))
@@ -39,16 +71,23 @@ def _deps_mtime() -> float:
 def _compile(src: str, force: bool, bf16: bool = False) -> str:
     obj = os.path.join(OBJ, src + (".bf16.o" if bf16 else ".o"))
     path = os.path.join(SRC, src)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _deps_mtime(),
-                                                                         os.path.getmtime(os.path.abspath(__file__))):
+    ru = obj + ".ru.txt"                       # the compiler's resource-usage remarks of this object (kept beside it)
+    if not force and os.path.exists(obj) and os.path.exists(ru) and \
+            os.path.getmtime(obj) > max(os.path.getmtime(path), _deps_mtime(), os.path.getmtime(os.path.abspath(__file__))):
+        check_resources(ru)
         return obj
-    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + (["-DOPUS_BF16"] if bf16 else []) + (["-x", "hip"] if src.endswith(".cpp") else []) + \
-          ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + [RU_FLAG] + EXTRA.get(src, []) + (["-DOPUS_BF16"] if bf16 else []) + \
+          (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    remarks = [l for l in r.stderr.splitlines() if RU_FLAG in l]
+    rest = "\n".join(l for l in r.stderr.splitlines() if RU_FLAG not in l)
+    with open(ru, "w") as f:
+        f.write("\n".join(remarks) + "\n")
+    if rest.strip():
+        sys.stderr.write(rest + "\n")
+    check_resources(ru)
     return obj
 
 

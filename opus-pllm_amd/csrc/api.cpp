@@ -200,7 +200,7 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_nunf = k.take<int32_t>((size_t)g.max_new_tokens + 4);
     c->d_eos = k.take<int32_t>(64);
     c->d_stop = k.take<int32_t>(16);
-    c->d_cnt = k.take<int32_t>(1024);                               // ticket counters of gemm_stream_kernel's in-launch combine (zero between launches)
+    c->d_cnt = k.take<int32_t>(HANDOFF_WORDS);                      // ticket / flag words of the in-launch hand-offs + the error word (GemmParams::combine_cnt)
     c->d_plan = k.take<int32_t>(4 * B + 8);
     c->d_pval = k.take<float>(64 * B);
     c->d_probs = k.take<float>(B * ((size_t)g.dec_vocab + 64 * 4));     // candidate probabilities (per-part slots)
@@ -306,7 +306,7 @@ extern "C" int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **ou
         for (size_t i = 0; i < t.size(); i += 2) { t[i] = 1.0f; t[i + 1] = 0.0f; }
     HIPC(hipMemcpy(c->cs_dec, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPC(hipMemset(c->d_step, 0, 16));
-    HIPC(hipMemset(c->d_cnt, 0, 1024 * sizeof(int32_t)));
+    HIPC(hipMemset(c->d_cnt, 0, HANDOFF_WORDS * sizeof(int32_t)));
     // the decode attention reads whole 32-slot tiles and masks afterwards: every cache slot must hold finite values
     HIPC(hipMemset(c->kc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
     HIPC(hipMemset(c->vc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
@@ -604,6 +604,7 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
     c->phase = PH_ENCODE;
     const int D = g.enc_dim, F = g.enc_ffn, nh = g.enc_heads, hd = D / nh;
     const int M = B * T;
+    HIPC(hipMemsetAsync(c->d_cnt, 0, HANDOFF_ERR * sizeof(int32_t), s));       // hand-off words start from zero on every call
     KL(KC_OTHER, 4.0 * M * D, launch_esm_embed(d_tokens, c->enc_emb, B, T, D, c->e_x, s));
     // Pre-LN blocks with the LayerNorm fused around the big tiled GEMM (GemmParams::ln_*): the epilogue that writes
     // the residual stream (wo, fc2) also leaves fp16(x) and per-row partial sums, a small kernel turns those into (mu, rstd),
@@ -691,6 +692,7 @@ static int ensure_proj_rows(opus_ctx *c, int B) {
 static int protein_projector_rows(opus_ctx *c, hipStream_t s, const float *d_pooled, int B, half_t *d_out) {
     const opus_config &g = c->cfg;
     const int De = g.enc_dim;
+    HIPC(hipMemsetAsync(c->d_cnt, 0, HANDOFF_ERR * sizeof(int32_t), s));
     if (!g.has_protein_projector) {
         // IdentityModule.protein_forward (opus_arch.py:70-80): the pooled embedding itself feeds the switch projector,
         // whose autocast Linear rounds it to fp16
@@ -871,6 +873,7 @@ static int lm_head_opt(opus_ctx *c, hipStream_t s, int B) {
 static int prefill_opt(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8_t *mask, int B, int T) {
     const opus_config &g = c->cfg;
     const int H = g.dec_dim, M = B * T;
+    HIPC(hipMemsetAsync(c->d_cnt, 0, HANDOFF_ERR * sizeof(int32_t), s));
     KL(KC_OTHER, 1.0 * M, launch_mask_to_kstart(mask, B, T, c->d_kstart, s));
     KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
     KL(KC_OTHER, 10.0 * M * H, launch_add_pos(c->d_x, c->dec_pos, c->d_kstart, nullptr, 0, B, T, H, g.dec_max_pos + 1, s));
@@ -902,6 +905,7 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
     const int H = g.dec_dim, F = g.dec_ffn, nh = g.dec_heads, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
     const int QKV = (nh + 2 * nkv) * hd, QD = nh * hd;
     const int M = B * T;
+    HIPC(hipMemsetAsync(c->d_cnt, 0, HANDOFF_ERR * sizeof(int32_t), s));       // hand-off words start from zero on every call
     KL(KC_OTHER, 1.0 * M, launch_mask_to_kstart(mask, B, T, c->d_kstart, s));
     KL(KC_OTHER, 6.0 * M * H, launch_h2f(embeds, c->d_x, (int64_t)M * H, s));
     // RMSNorm fused around the big tiled GEMM, as the encoder's LayerNorm (GemmParams::ln_* with mu = 0): the wo / down epilogue
@@ -1003,7 +1007,7 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     const bool down_tiled = rowscale && (F & 63) == 0 && gemm_stream_would(B, H, F, 0, 1, 0, c->gemm_ws_bytes);
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, rowscale ? c->d_xln : nullptr,
                                                   rowscale ? c->d_ssq : nullptr, qkv_tiled ? 1 : 0, c->cs_dec, c->d_kstart, c->d_step, T,
-                                                  hd / 2, c->cs_row, s));
+                                                  hd / 2, c->cs_row, c->d_cnt, HANDOFF_ERR, s));     // (+ zeroes the hand-off words)
     c->xln_tiled = qkv_tiled;
     c->xh_src = rowscale ? c->d_xl : nullptr;
     if (rowscale) c->ssq_nblk = H >> 8;
@@ -1046,6 +1050,23 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     OPC(lm_head(c, s, B));
     KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
     return OPUS_OK;
+}
+
+// Synchronises `s` and reports an in-launch hand-off that gave up waiting (GemmParams::combine_cnt[HANDOFF_ERR], set by a kernel
+// whose bounded wait ran out: poisoned ticket words, a partner that never arrived).  The results of that call are not to be used.
+static int handoff_check(opus_ctx *c, hipStream_t s) {
+    int32_t err = 0;
+    HIPC(hipMemcpyAsync(&err, c->d_cnt + HANDOFF_ERR, sizeof(err), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    if (!err) return OPUS_OK;
+    HIPC(hipMemsetAsync(c->d_cnt, 0, HANDOFF_WORDS * sizeof(int32_t), s));
+    return fail(OPUS_EHIP, "an in-launch hand-off (split-K combine) gave up waiting for its partner: results of this call are invalid");
+}
+
+extern "C" int opus_check_error(opus_ctx *c, void *stream) {
+    if (!c) return fail(OPUS_EBADARG, "ctx is null");
+    HIPC(hipSetDevice(c->device));
+    return handoff_check(c, (hipStream_t)stream);
 }
 
 static int check_prefill_args(opus_ctx *c, const void *e, const uint8_t *m, int B, int T) {
@@ -1174,7 +1195,7 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
         }
     }
     HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)produced * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIPC(hipStreamSynchronize(s));
+    OPC(handoff_check(c, s));                                         // (synchronises the stream)
     int n = produced;
     for (int k = 0; k < produced; ++k) if (nunf[k] == 0) { n = k + 1; break; }
     *n_out = n;
@@ -1356,6 +1377,16 @@ extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
     if (!strcmp(name, "no_stream")) g_knobs.no_stream = value;
     else if (!strcmp(name, "debug_a_tiled")) g_knobs.debug_a_tiled = value;
     else if (!strcmp(name, "no_ln_fusion")) g_knobs.no_ln_fusion = value;
+    else if (!strcmp(name, "poison_handoff")) {   // test aid: what an aborted launch leaves behind - every ticket drawn once, no flag set
+        if (!c) return fail(OPUS_EBADARG, "poison_handoff needs a context");
+        std::vector<int32_t> h(HANDOFF_ERR, 0);
+        // (a ticket count alone cannot tell "one stale ticket + three arrivals" from four arrivals: detection is certain only for
+        //  values no clean launch can reach - value > 1 writes that into the tickets -; the cure is the per-call zeroing)
+        if (value) for (int i = 0; i < HANDOFF_ERR; ++i) h[i] = i < 512 ? value : ((i & 1) ? 0 : 1);
+        HIPC(hipSetDevice(c->device));
+        HIPC(hipDeviceSynchronize());
+        HIPC(hipMemcpy(c->d_cnt, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     else if (!strcmp(name, "pp_gm")) { if (value < 1 || value > 64) return fail(OPUS_EBADARG, "pp_gm out of range"); g_knobs.pp_gm = value; }
     else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '7' && !name[5]) g_knobs.misc[name[4] - '0'] = value;
     else return fail(OPUS_EBADARG, "debug_knob: unknown knob '%s'", name);

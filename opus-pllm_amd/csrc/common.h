@@ -102,6 +102,9 @@ __host__ __device__ __forceinline__ int64_t tiled_off(int row, int k, int K) {
     return ((int64_t)(row >> 4) * (K >> 6) + (k >> 6)) * 1024 + ((k & 63) >> 5) * 512 + ((((k & 31) >> 3) << 4) + (row & 15)) * 8 + (k & 7);
 }
 
+constexpr int HANDOFF_WORDS = 1024, HANDOFF_ERR = 1023;
+constexpr int HANDOFF_SPIN_LIMIT = 1 << 19;   // polls (s_sleep(4) + one L2 round trip each: >= 0.3 s) before a waiter gives up
+
 struct GemmParams {
     const half_t *A;        // fp16 activations [M,K] (row-major, lda), or
     const float *Af;        // fp32 residual stream [M,K]: fused RMSNorm (skinny kernel only), else nullptr
@@ -151,7 +154,10 @@ struct GemmParams {
     // xh_tiled / c_tiled: write xh_out / the fp16 output C that way (for a consumer that will read it with a_tiled).
     int a_tiled = 0, xh_tiled = 0, c_tiled = 0;
     // gemm_stream_kernel with k-parts and a finished output: ticket counters (one int per column group, all zero between
-    // launches) of the in-launch combine; nullptr: slabs + a split-K reduce launch
+    // launches) of the in-launch combine; nullptr: slabs + a split-K reduce launch.  HANDOFF_WORDS ints: [0, 512) tickets of
+    // gemm_stream_kernel, [512, HANDOFF_ERR) (ticket, flag) pairs of gemm_pp_kernel's two-part tail tiles, [HANDOFF_ERR] the
+    // error word a hand-off sets when its bounded wait runs out (the host reads it at its next synchronisation: OPUS_EHIP).
+    // Everything below HANDOFF_ERR is zeroed at the head of every encode / prefill / decode step.
     int *combine_cnt = nullptr;
     // LayerNorm fused around the big tiled GEMM (gemm_pp_kernel; the encoder's pre-LN blocks).  With the norm
     // weight folded into the consumer's weight W' = W diag(gamma) and beta into its bias c2 = W beta + b,
@@ -264,7 +270,7 @@ hipError_t launch_h2f(const half_t *in, float *out, int64_t n, hipStream_t s);
 // ... and (cs != nullptr) the rotary rows of this step: cs_row[b][d] = cs[T0 + *step - kstart[b]][d], d < half (float2 each)
 hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
                                int xh_tiled, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int half,
-                               float *cs_row, hipStream_t s);
+                               float *cs_row, int *cnt, int ncnt, hipStream_t s);
 hipError_t launch_add_pos(float *x, const half_t *pos, const int32_t *kstart, const int32_t *step, int t0, int B, int Tq,
                           int H, int max_idx, hipStream_t s);
 hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hipStream_t s);

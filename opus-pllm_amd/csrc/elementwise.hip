@@ -183,8 +183,13 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__rest
                                                            int H, int V, float *__restrict__ x, half_t *__restrict__ xh,
                                                            float *__restrict__ ssq, int xh_tiled, const float *__restrict__ cs,
                                                            const int32_t *__restrict__ kstart, const int32_t *__restrict__ step,
-                                                           int T0, int half, float *__restrict__ cs_row) {
+                                                           int T0, int half, float *__restrict__ cs_row, int *__restrict__ cnt, int ncnt) {
     const int b = blockIdx.x;
+    // first kernel of every decode step: the ticket / flag words of the step's in-launch hand-offs start from zero whatever an
+    // earlier launch left behind (cdna_hip_programming.md Guideline 16 "Re-initialise every call"; the last arriver's re-arm alone
+    // never recovers from one bad launch).  Ordered before the step's GEMMs by the kernel boundary.
+    if (cnt && b == 0)
+        for (int i = threadIdx.x; i < ncnt; i += 256) cnt[i] = 0;
     if (cs) {   // rotary (cos, sin) row of this batch row's position in this step, for every attention launch of the step
         const int pos = T0 + *step - kstart[b];
         for (int d = threadIdx.x; d < half; d += 256)
@@ -211,10 +216,10 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__rest
 }
 hipError_t launch_embed_tokens(const int32_t *tok, const half_t *emb, int B, int H, int V, float *x, half_t *xh, float *ssq,
                                int xh_tiled, const float *cs, const int32_t *kstart, const int32_t *step, int T0, int half,
-                               float *cs_row, hipStream_t s) {
+                               float *cs_row, int *cnt, int ncnt, hipStream_t s) {
     if (xh && (H & 255)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), 0, s, tok, emb, H, V, x, xh, ssq, xh_tiled, cs, kstart, step, T0, half,
-                       cs_row);
+                       cs_row, cnt, ncnt);
     return hipGetLastError();
 }
 

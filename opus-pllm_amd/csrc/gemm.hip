@@ -954,6 +954,12 @@ __host__ __device__ __forceinline__ void pp_tile_coords(int id, int tiles_m, int
     tm = grp * GM + rem_id % rows_here;
     tn = rem_id / rows_here;
 }
+template <int EPI, bool LNA>
+__device__ __forceinline__ void pp_finish(const GemmParams &p, f4 (&acc)[8][4], char *smem, const int wave, const int m0, const int n0,
+                                          const int bid, const int full_tiles, const int tail_split, const int kpart, const bool partial);
+template <int EPI, bool LNA>
+__device__ __forceinline__ void pp_epilogue(const GemmParams &p, f4 (&acc)[8][4], char *smem, const int wave, const int m0, const int n0,
+                                            const char *pair_slab);
 // LNA: consumer side of the fused LayerNorm (GemmParams::ln_stat / ln_colsum): y = rstd (acc - mu s) + c2 in the epilogue
 template <int EPI, bool LNA = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m, int tiles_n, int full_tiles, int tail_split) {
@@ -995,8 +1001,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
 
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
-    // DMA sources of this wave's two 1-KB pieces (q = 2 wave + j) of each kind of half-tile
-    const half_t *srcA[2][2], *srcB[2][2];
+    // DMA sources of this wave's two 1-KB pieces (q = 2 wave + j) of each kind of half-tile: 32-bit BYTE offsets from the
+    // (scalar) matrix bases - the K-tile advance goes into the scalar base, so the main loop keeps 8 address registers instead
+    // of 16 (it runs at the 256-register limit; the launcher refuses operands beyond 4 GB)
+    unsigned offA[2][2], offB[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = 2 * wave + j;
@@ -1006,22 +1014,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         for (int rh = 0; rh < 2; ++rh) {
             int row = m0 + (lr >> 6) * 128 + rh * 64 + (lr & 63);
             row = row < p.M ? row : p.M - 1;
-            srcA[j][rh] = p.A + (int64_t)row * p.lda + chunk * 8 + (int64_t)kt0 * 64;
+            offA[j][rh] = (unsigned)(((int64_t)row * p.lda + chunk * 8) * 2);
         }
         const int pi = q >> 1, s = q & 1;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             int pn = (n0 >> 4) + (pi >> 1) * 4 + ch * 2 + (pi & 1);
             pn = pn < npanels ? pn : npanels - 1;
-            srcB[j][ch] = p.W + ((int64_t)pn * KT_all + kt0) * 1024 + s * 512 + lane * 8;
+            offB[j][ch] = (unsigned)((((int64_t)pn * KT_all) * 1024 + s * 512 + lane * 8) * 2);
         }
     }
+    const char *baseA = reinterpret_cast<const char *>(p.A) + (int64_t)kt0 * 128;
+    const char *baseB = reinterpret_cast<const char *>(p.W) + (int64_t)kt0 * 2048;
     auto issue_half = [&](int hq) {
         const int kt = hq >> 2, i = hq & 3;
         char *dst = smem + (hq & 7) * HT + (2 * wave) * 1024;
+        const char *sa = baseA + (int64_t)kt * 128, *sb = baseB + (int64_t)kt * 2048;     // scalar
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const half_t *src = (i == 0 || i == 3) ? srcA[j][i == 3] + (int64_t)kt * 64 : srcB[j][i == 2] + (int64_t)kt * 1024;
+            const char *src = (i == 0 || i == 3) ? sa + offA[j][i == 3] : sb + offB[j][i == 2];
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
         }
     };
@@ -1129,7 +1140,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                        // every wave executes the same number of barriers
     if (p.trace && tid == 0) p.trace[blockIdx.x * 4 + 2] = wall_clock64();
+    pp_finish<EPI, LNA>(p, acc, smem, wave, m0, n0, bid, full_tiles, tail_split, kpart, partial);
+}
 
+// Everything behind the main loop of gemm_pp_kernel: the in-launch pair combine of a two-part tail tile, the raw slab of a
+// k-part, the epilogue.  The main loop runs at the 256-register limit (128 accumulators + 96 operand fragments + DMA
+// addresses), so nothing but the accumulators and wave-uniform values (scalar registers) crosses this boundary: the lane's
+// coordinates are re-derived here from v_mbcnt (an asm the compiler cannot match with the thread id it was handed at entry, so
+// that id is dead behind the prologue instead of being spilled around the loop).  Inlined: the accumulators stay where they are.
+template <int EPI, bool LNA>
+__device__ __forceinline__ void pp_finish(const GemmParams &p, f4 (&acc)[8][4], char *smem, const int wave, const int m0, const int n0,
+                                          const int bid, const int full_tiles, const int tail_split, const int kpart, const bool partial) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int tid = wave * 64 + lane;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+
+    const char *pair_slab = nullptr;                                  // (uniform) the partner's published accumulators, if any
     if (partial && tail_split == 2 && p.combine_cnt) {
         // Two k-parts: combined INSIDE the launch, and the tile finished by this kernel's own epilogue.  The workgroup of the
         // pair that finishes its half first publishes its accumulators (write-through stores, drained, then a flag); the other
@@ -1144,6 +1172,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         __syncthreads();
         const int order = *word;                                      // uniform
         __syncthreads();
+        if (order > 1 && tid == 0)                                    // a third ticket: the word was poisoned (an aborted launch)
+            __hip_atomic_store(p.combine_cnt + HANDOFF_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ws + ((int64_t)tt << 16)), 0, 1 << 18, 0x00020000);
         if (order == 0) {
 #pragma unroll
@@ -1157,27 +1187,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
             return;
         }
         if (tid == 0) {
-            while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+            // bounded: the partner drew the first ticket, so it is running and needs nobody - unless the words were poisoned by an
+            // aborted launch; then this waiter gives up, tells the host (error word -> OPUS_EHIP at its next synchronisation) and
+            // finishes with whatever the slab holds instead of hanging the GPU
+            int spins = 0;
+            while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > HANDOFF_SPIN_LIMIT) {
+                    __hip_atomic_store(p.combine_cnt + HANDOFF_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
             __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed for the next launch
             __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        // the partner's accumulators: global -> LDS by DMA (no staging registers: the kernel is at its register limit), this
-        // wave's 32 KB in two halves through its 16 KB of the idle ring, then added in place
-        {
-            const char *sb = reinterpret_cast<const char *>(p.ws + ((int64_t)tt << 16));
-            char *myl = smem + wave * 16384;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(sb + ((int64_t)((h * 16 + q) * 512 + tid)) * 16), (lptr_t)(myl + q * 1024), 16, 0, 16);   // aux 16 = sc1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[(h * 16 + q) >> 2][(h * 16 + q) & 3] += *reinterpret_cast<const f4 *>(myl + q * 1024 + lane * 16);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
+        // The partner's accumulators are NOT added here: the epilogue adds them row tile by row tile (pair_slab below), eight
+        // 16-byte write-through-coherent (sc1) loads per lane and pair of row tiles, requested one pair ahead.  Added into the
+        // accumulators in one piece, the 128 sums were new values that had to be copied back into the registers the epilogue
+        // expects where this path joins the plain one: 64 moves on EVERY tile and 9-12 spilled registers (round 3).
+        pair_slab = reinterpret_cast<const char *>(p.ws + ((int64_t)tt << 16));
     } else if (partial) {   // raw fp32 tile [256][256] of this k-part (rows / columns beyond M / N hold clamped-row products: never read)
         float *slab = p.ws + (((int64_t)(bid - full_tiles) * tail_split + kpart) << 16);
 #pragma unroll
@@ -1190,6 +1219,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         return;
     }
     // ---- epilogue ----
+    // (the lane's coordinates once more, from an asm placed HERE: every per-lane address of the epilogue then depends on a value
+    //  that does not exist before this point, so the compiler cannot hoist that arithmetic - ~50 registers of it - above the
+    //  pair combine, where the 128 accumulators and the partner's tile already fill the register file)
+    pp_epilogue<EPI, LNA>(p, acc, smem, wave, m0, n0, pair_slab);
+}
+
+template <int EPI, bool LNA>
+__device__ __forceinline__ void pp_epilogue(const GemmParams &p, f4 (&acc)[8][4], char *smem, const int wave, const int m0, const int n0,
+                                            const char *pair_slab) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int tid = wave * 64 + lane;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
     // The accumulators hold 4 consecutive columns of 16 different rows per lane group: stored directly, a wave-wide
     // store touches 16 rows x 32-B pieces.  The LDS is idle now, so each wave turns its 16-row x 64-column slabs
     // through a private LDS patch and writes / reads-modifies-writes whole 16-B-per-lane row segments instead.
@@ -1197,17 +1240,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     const int nlim = EPI == EPI_SILU_GU16 ? p.N / 2 : p.N;
     const int nw0 = EPI == EPI_SILU_GU16 ? (n0 >> 1) + wc * 32 : n0 + wc * 64;   // first output column of this wave
     const bool rows16 = ((p.ldc & 7) == 0) && ((p.ldr & 3) == 0) && nw0 + NO <= nlim;
+    // the partner's accumulators of a two-part tail tile, as published: element (i, j) of thread t at ((4 i + j) 512 + t) 16 bytes
+    const __amdgpu_buffer_rsrc_t psrs = __builtin_amdgcn_make_buffer_rsrc((void *)pair_slab, 0, pair_slab ? 1 << 18 : 0, 0x00020000);
+    auto pair_load = [&](int i, int j) {
+        return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(psrs, ((i * 4 + j) * 512 + tid) * 16, 0, 16));   // aux 16 = sc1
+    };
     if (!rows16) {                                                    // ragged right edge / odd strides: element-wise path
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            f4 av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = acc[i][j];
+            if (pair_slab) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] += pair_load(i, j);
+            }
             const int m = m0 + wr * 128 + i * 16 + li;
             if (m >= p.M) continue;
             if (EPI == EPI_SILU_GU16) {
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wc * 64 + jj * 32 + 4 * g, acc[i][2 * jj], acc[i][2 * jj + 1]);
+                for (int jj = 0; jj < 2; ++jj) store4<EPI>(p, m, n0 + wc * 64 + jj * 32 + 4 * g, av[2 * jj], av[2 * jj + 1]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wc * 64 + j * 16 + 4 * g, acc[i][j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) store4<EPI>(p, m, n0 + wc * 64 + j * 16 + 4 * g, av[j], av[j]);
             }
         }
         return;
@@ -1228,7 +1283,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     float bz[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) bz[q] = 0.f;
-    if (p.bias && !LNA) {
+    // (only the gate / up epilogue keeps its bias in registers: the others read it back from LDS per row tile - see `cb` below -,
+    //  which is what lets the fp32 + residual modes hold the pair combine's 16 registers beside 128 + 64)
+    if (p.bias && !LNA && EPI == EPI_SILU_GU16) {
         if (EPI == EPI_SILU_GU16) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
@@ -1255,9 +1312,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
         m = m < p.M ? m : p.M - 1;
         st = reinterpret_cast<const float2 *>(p.ln_stat)[m];
     };
-    if constexpr (LNA && EPI != EPI_SILU_GU16) {
-        cb[lane] = p.bias ? p.bias[n0 + wc * 64 + lane] : 0.f;
-        cb[64 + lane] = p.ln_colsum ? p.ln_colsum[n0 + wc * 64 + lane] : 0.f;   // (nullptr: RMSNorm, mu = 0)
+    if constexpr (EPI != EPI_SILU_GU16) {
+        const int nc = n0 + wc * 64 + lane;
+        cb[lane] = (p.bias && nc < p.N) ? p.bias[nc] : 0.f;
+        if constexpr (LNA) cb[64 + lane] = p.ln_colsum ? p.ln_colsum[nc] : 0.f;   // (nullptr: RMSNorm, mu = 0)
     }
     if constexpr (LNA) {
         load_stat(0, lst[0][0]);
@@ -1320,8 +1378,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     typedef unsigned int u2v __attribute__((ext_vector_type(2)));
     enum { M_F16 = 0, M_F32RES = 1, M_F32RES_LN = 2, M_ROPE = 3, M_GENERIC = 4 };
-    auto run = [&](auto mode_tag) {
+    auto run = [&](auto mode_tag, auto pair_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
+        // PAIR: the loop of a two-part tail tile that also adds its partner's half (pair_slab).  A separate instance, so that the
+        // loop every other tile runs is exactly the one without it; its next-pair prefetch is issued BEHIND the current pair
+        // (fp32 + residual epilogues hold 128 accumulators + 2 x 32 residual registers: the partner's 16 fit only while one of
+        // the two residual stages is empty).
+        constexpr bool PAIR = decltype(pair_tag)::value;
         constexpr bool RES = MODE == M_F32RES || MODE == M_F32RES_LN;          // fp32 output + fp32 residual
         constexpr bool CS = MODE == M_ROPE;
         float4 rbuf[2][RB][NR];
@@ -1344,21 +1407,42 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
             }
         };
         prefetch(0);
+        f4 pb[4];                                                         // the partner's share of the NEXT row tile (one tile ahead)
+        auto pair_fetch = [&](int i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pb[j] = pair_load(i, j);
+        };
+        // (the pair combine exists in the modes of the path - fp16 output, fp32 + residual (+ LayerNorm partials); the launcher sends
+        //  two-part tiles of any other epilogue through the reduce kernel: launch_pp, `pair`)
+        if constexpr (PAIR) pair_fetch(0);
 #pragma unroll
         for (int ib = 0; ib < 8 / RB; ++ib) {
-            if (ib + 1 < 8 / RB) prefetch(ib + 1);
+            if constexpr (!PAIR) {
+                if (ib + 1 < 8 / RB) prefetch(ib + 1);
+            }
             // 1. bias / activation in registers, 4 columns per lane -> patch image u, row li
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int i = ib * RB + u;
                 float *pu = patch + u * PIMG;
+                // this row tile's sums: the accumulators as they stand, plus the partner's half on a two-part tail tile (a + b is the
+                // same fp32 number whichever half waits).  A copy, so that only these 16 registers - not the accumulator file -
+                // have two definitions where the two cases meet.
+                f4 av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = acc[i][j];
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[j] += pb[j];
+                    if (i + 1 < 8) pair_fetch(i + 1);                     // (16 registers, re-used at once for the next row tile)
+                }
                 if (EPI == EPI_SILU_GU16) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         f4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float gate = acc[i][2 * jj][r], up = acc[i][2 * jj + 1][r];
+                            float gate = av[2 * jj][r], up = av[2 * jj + 1][r];
                             if constexpr (LNA) {                     // RMSNorm row scale (no bias in the gate / up projections)
                                 gate *= lst[ib & 1][u].y;
                                 up *= lst[ib & 1][u].y;
@@ -1373,21 +1457,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
                 } else {
                     // (LNA: the 8 LDS reads of this row tile's bias / column-sum values are issued together, ahead of the patch
                     //  writes: read-wait-compute-write per 16 columns serialised the LDS queue, ~3 us per tile)
-                    f4 b4[LNA ? 4 : 1], c4[LNA ? 4 : 1];
-                    if constexpr (LNA) {
+                    f4 b4[4], c4[LNA ? 4 : 1];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            b4[j] = *reinterpret_cast<const f4 *>(cb + j * 16 + 4 * g);
-                            c4[j] = *reinterpret_cast<const f4 *>(cb + 64 + j * 16 + 4 * g);
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        b4[j] = *reinterpret_cast<const f4 *>(cb + j * 16 + 4 * g);
+                        if constexpr (LNA) c4[j] = *reinterpret_cast<const f4 *>(cb + 64 + j * 16 + 4 * g);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        f4 v = acc[i][j];
+                        f4 v = av[j];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if constexpr (LNA) v[r] = __builtin_fmaf(lst[ib & 1][u].y, v[r] - lst[ib & 1][u].x * c4[j][r], b4[j][r]);
-                            else v[r] += bz[j * 4 + r];
+                            else v[r] += b4[j][r];
                             if (EPI == EPI_GELU) v[r] = gelu_erf(v[r]);
                         }
                         *reinterpret_cast<f4 *>(pu + pidx(li, j * 16 + 4 * g)) = v;
@@ -1470,20 +1552,36 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p, int tiles_m,
             }
             // the patch images are rewritten by the next pair of row tiles: the reads above must have retired (same wave, in order)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (PAIR) {
+                if (ib + 1 < 8 / RB) prefetch(ib + 1);
+            }
         }
     };
+    typedef std::false_type NP;
+    typedef std::true_type WP;
+    // (the pair combine exists in the modes of the path - fp16 output, fp32 + residual (+ LayerNorm partials); the launcher sends
+    //  two-part tiles of any other epilogue through the reduce kernel: launch_pp, `pair`)
     if constexpr (LNA) {                                               // (the host side guarantees fp16 output, no residual)
-        if (rope_on) run(std::integral_constant<int, ROPE_OK ? M_ROPE : M_F16>{});
-        else run(std::integral_constant<int, M_F16>{});
+        if (rope_on) run(std::integral_constant<int, ROPE_OK ? M_ROPE : M_F16>{}, NP{});
+        else if (pair_slab) run(std::integral_constant<int, M_F16>{}, WP{});
+        else run(std::integral_constant<int, M_F16>{}, NP{});
     } else if constexpr (EPI != EPI_NONE) {                            // GELU / gate-up epilogues: fp16 output on the path
-        if (!p.out_f32 && !p.residual) run(std::integral_constant<int, M_F16>{});
-        else run(std::integral_constant<int, M_GENERIC>{});
+        if (!p.out_f32 && !p.residual) {
+            if (pair_slab) run(std::integral_constant<int, M_F16>{}, WP{});
+            else run(std::integral_constant<int, M_F16>{}, NP{});
+        } else run(std::integral_constant<int, M_GENERIC>{}, NP{});
     } else {
-        if (rope_on) run(std::integral_constant<int, M_ROPE>{});
-        else if (!p.out_f32 && !p.residual) run(std::integral_constant<int, M_F16>{});
-        else if (p.out_f32 && p.residual && p.ln_part) run(std::integral_constant<int, M_F32RES_LN>{});
-        else if (p.out_f32 && p.residual) run(std::integral_constant<int, M_F32RES>{});
-        else run(std::integral_constant<int, M_GENERIC>{});
+        if (rope_on) run(std::integral_constant<int, M_ROPE>{}, NP{});
+        else if (!p.out_f32 && !p.residual) {
+            if (pair_slab) run(std::integral_constant<int, M_F16>{}, WP{});
+            else run(std::integral_constant<int, M_F16>{}, NP{});
+        } else if (p.out_f32 && p.residual && p.ln_part) {
+            if (pair_slab) run(std::integral_constant<int, M_F32RES_LN>{}, WP{});
+            else run(std::integral_constant<int, M_F32RES_LN>{}, NP{});
+        } else if (p.out_f32 && p.residual) {
+            if (pair_slab) run(std::integral_constant<int, M_F32RES>{}, WP{});
+            else run(std::integral_constant<int, M_F32RES>{}, NP{});
+        } else run(std::integral_constant<int, M_GENERIC>{}, NP{});
     }
     if (p.trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1678,7 +1776,8 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
         }
     }
     // two k-parts: combined in the launch (gemm_pp_kernel); knob misc6 = 1: slabs + pp_tail_reduce_kernel as for more parts
-    const bool pair = split == 2 && p.combine_cnt && !g_knobs.misc[6];
+    const bool pair_mode = (!p.out_f32 && !p.residual) || (p.out_f32 && p.residual);   // the epilogue modes that carry the combine
+    const bool pair = split == 2 && p.combine_cnt && !g_knobs.misc[6] && pair_mode && (p.ldc & 7) == 0 && (p.ldr & 3) == 0 && (p.N & 255) == 0;
     if (!pair) p.combine_cnt = nullptr;
     OPUS_LAUNCH(KC_PP, kern, dim3(full + tail * split), dim3(512), 8 * 16384, s, p, bm, bn, full, split);
     hipError_t e = hipGetLastError();

@@ -238,6 +238,8 @@ __global__ __launch_bounds__(NT) void gemm_stream_kernel(GemmParams p, int kspli
     if (tid == 0) *flag = __hip_atomic_fetch_add(p.combine_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (p.trace && tid == 0) p.trace[wg * 8 + 7] = wall_clock64();       // (ticket drawn)
+    if (*flag >= ksplit && tid == 0)                     // a ticket no clean launch can draw: the word was poisoned (an aborted launch)
+        __hip_atomic_store(p.combine_cnt + HANDOFF_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (*flag != ksplit - 1) return;                     // uniform
     if (tid == 0) __hip_atomic_store(p.combine_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // all slab loads of this wave's tiles are requested together (k-parts in groups of 4), then added in k-part order

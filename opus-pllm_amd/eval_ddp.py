@@ -39,7 +39,9 @@ def annotate(model, tokenizer, items, input_path, batch_size, max_new, temperatu
     logits_out (a list, --dump_logits): receives the fp32 [b, V] logits of each batch's last decode step (model.last_logits).
     inflight (--inflight): batches in flight on this GPU.  The reference's loop is strictly sequential; with n > 1, n contexts
     that share the model's weights (model.new_context()) take the batches round-robin from n host threads - batches are
-    independent, results come back in input order and are the same ids as with one context."""
+    independent, results come back in input order and are the same ids as with one context: greedy ids because the kernels are
+    the same, sampled ids because every batch's sampler seed is drawn HERE, in input order, from torch's global generator
+    (torch.manual_seed reproduces a run whatever `inflight` is) and handed to generate(seed=...)."""
     dev = device or model.device
     prot_all = None
     if use_input_embed and items:
@@ -47,6 +49,9 @@ def annotate(model, tokenizer, items, input_path, batch_size, max_new, temperatu
     starts = list(range(0, len(items), batch_size))
     outs = [None] * len(starts)
     last = [None] * len(starts)
+    # one sampler seed per batch, drawn in input order before any worker thread starts (generate() would otherwise draw it from
+    # the global generator at call time: with two threads racing, which batch got which seed depended on thread scheduling)
+    seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in starts] if temperature > 0 else [None] * len(starts)
 
     def one(m, j):
         i = starts[j]
@@ -59,7 +64,8 @@ def annotate(model, tokenizer, items, input_path, batch_size, max_new, temperatu
         with torch.inference_mode():
             out = m.generate(ids, [q["input"] for q in batch], attention_mask=mask, pad_token_id=tokenizer.eos_token_id,
                              do_sample=temperature > 0, temperature=temperature, top_p=top_p,
-                             num_beams=num_beams, max_new_tokens=max_new, use_cache=True, stop_sequence=stop_sequence, **extra)
+                             num_beams=num_beams, max_new_tokens=max_new, use_cache=True, stop_sequence=stop_sequence,
+                             seed=seeds[j], **extra)
         if logits_out is not None:
             last[j] = m.last_logits(len(batch))
         full = torch.full((out.shape[0], max_new), tokenizer.eos_token_id, dtype=torch.long, device=dev)
@@ -78,8 +84,12 @@ def annotate(model, tokenizer, items, input_path, batch_size, max_new, temperatu
         def worker(k):
             try:
                 torch.cuda.set_device(dev)
-                for j in range(k, len(starts), n_ctx):
-                    one(ctxs[k], j)
+                # a torch stream of this thread's own: the context orders its work against torch.cuda.current_stream(), which
+                # would otherwise be the one default stream of the process and serialise context A's enqueued work in front of B's
+                with torch.cuda.stream(torch.cuda.Stream(dev)):
+                    for j in range(k, len(starts), n_ctx):
+                        one(ctxs[k], j)
+                    torch.cuda.current_stream(dev).synchronize()      # results are read from the caller's stream
             except BaseException as e:      # noqa: BLE001  (re-raised on the caller's thread)
                 errs.append(e)
         threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_ctx)]

@@ -427,7 +427,7 @@ def test_stream_gemm_vs_fp64(big64, M, N, K, tiled):
         assert bool(torch.isfinite(out).all())
         err = (out.double().cpu() - ref).abs().max().item()
         assert err <= 2e-3 * ref.abs().max().item(), err
-        for _ in range(3):                                       # k-parts are combined by whichever workgroup arrives last:
+        for _ in range(8 if K > 8192 and M > 16 else 3):         # k-parts are combined by whichever workgroup arrives last:
             again, _ = run(M, True, tiled)                       # the sums are taken in k-part order all the same
             assert torch.equal(again, out)
         if 2 * 64 * K <= (600 if tiled else 280) * 1024:         # the same rows inside a 64-row launch: bit-identical
@@ -585,3 +585,64 @@ def test_prefill_last_layer_tail_on_last_rows_only(big64):
     assert r0 < ROW_VS_BATCH_LOGITS and r1 < ROW_VS_BATCH_LOGITS, (r0, r1)
     decisive = _margin(out[1][0]) > MARGIN_TAU
     assert torch.equal(out[0][0].argmax(-1)[decisive], out[1][0].argmax(-1)[decisive])
+
+
+def test_poisoned_handoff_words_fail_closed(big64):
+    """The in-launch split-K hand-offs (gemm_stream_kernel's ticket, gemm_pp_kernel's pair flag) wait only for running
+    workgroups, with a bounded wait.  Hand-off words left as an aborted launch would leave them (every ticket drawn once, no
+    flag set; knob `poison_handoff`) must end in an ERROR CODE - not in a hang, not in silently wrong sums - and the path
+    must recover by itself: every encode / projector / prefill / decode step re-zeroes the words (run once: the poisoned pair
+    waits out its bound, ~0.5 s)."""
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model = big64
+    dev = model.device
+    lib = _cabi.lib()
+    g = torch.Generator().manual_seed(99)
+    # (a) gemm_stream_kernel, down shape at 64 rows: 4 panels x 4 k-parts, combined by the last arriver of a ticket
+    M, N, K = 64, 4096, 14336
+    A = _tile_rows((torch.randn(M, K, generator=g) * 0.5).half().to(dev))
+    W = tile_weight(((torch.randn(N, K, generator=g) / K ** 0.5).half()).to(dev))
+    x = torch.zeros(M, N, device=dev)
+    _cabi.check(lib.opus_check_error(model._ctx, None))
+    try:
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 1))
+        _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), None, x.data_ptr(), x.data_ptr(), M, N, K, 0, 1, None))
+        _cabi.check(lib.opus_check_error(model._ctx, None))                 # clean words: no error
+        good = x.clone()
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"poison_handoff", 8))    # (tickets no clean launch can draw: always detected)
+        x.zero_()
+        _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), None, x.data_ptr(), x.data_ptr(), M, N, K, 0, 1, None))
+        with pytest.raises(_cabi.OpusError) as ei:
+            _cabi.check(lib.opus_check_error(model._ctx, None))
+        assert ei.value.code == -3 and "hand-off" in str(ei.value)
+        _cabi.check(lib.opus_check_error(model._ctx, None))                 # the check cleared the words
+        x.zero_()
+        _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), None, x.data_ptr(), x.data_ptr(), M, N, K, 0, 1, None))
+        torch.cuda.synchronize()
+        assert torch.equal(x, good)
+    finally:
+        _cabi.check(lib.opus_debug_knob(model._ctx, b"debug_a_tiled", 0))
+    # (b) gemm_pp_kernel, prefill wo shape: 128 tail tiles in two k-parts, the later half waits for its partner's flag
+    M, N, K = 6144, 4096, 3072
+    A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+    W = tile_weight(((torch.randn(N, K, generator=g) / K ** 0.5).half()).to(dev))
+    out = torch.zeros(M, N, dtype=torch.float16, device=dev)
+    _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 0, None))
+    _cabi.check(lib.opus_check_error(model._ctx, None))
+    good = out.clone()
+    _cabi.check(lib.opus_debug_knob(model._ctx, b"poison_handoff", 1))
+    _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 0, None))
+    with pytest.raises(_cabi.OpusError):
+        _cabi.check(lib.opus_check_error(model._ctx, None))                 # (returns after the bounded wait, not never)
+    # (c) the path itself never sees stale words: poisoned again, a whole generate() is clean and equals the unpoisoned run
+    seqs = [synth.synth_protein(64, i) for i in range(8)]
+    ids = _prompts(cfg, 8)
+    ref = model.generate(ids, seq=seqs, max_new_tokens=4)
+    _cabi.check(lib.opus_debug_knob(model._ctx, b"poison_handoff", 1))
+    again = model.generate(ids, seq=seqs, max_new_tokens=4)
+    assert torch.equal(ref, again)
+    out.zero_()
+    _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 0, None))
+    _cabi.check(lib.opus_check_error(model._ctx, None))
+    assert torch.equal(out, good)

@@ -273,6 +273,15 @@ def test_two_stage_eval_loop_projects_the_shard_once(tmp_path):
     b = ddp.annotate(model, tok, items, "", 4, 8, logits_out=lg2, inflight=2)
     assert torch.equal(a, one) and torch.equal(b, one)
     assert len(lg1) == len(lg2) == 3 and all(torch.equal(x, y) for x, y in zip(lg1, lg2))
+    # sampling (the driver's default, temperature 0.1): the per-batch seeds are drawn in input order before the worker threads
+    # start, so a run is reproducible under torch.manual_seed and does not depend on --inflight
+    draws = []
+    for infl in (1, 2, 2):
+        torch.manual_seed(77)
+        draws.append(ddp.annotate(model, tok, items, "", 4, 8, temperature=0.9, top_p=0.95, inflight=infl))
+    assert torch.equal(draws[0], draws[1]) and torch.equal(draws[1], draws[2])
+    torch.manual_seed(78)
+    assert not torch.equal(ddp.annotate(model, tok, items, "", 4, 8, temperature=0.9, top_p=0.95, inflight=2), draws[0])
 
 
 @pytest.mark.gpu
