@@ -71,7 +71,9 @@ def parse(argv=None):
     p.add_argument("--model", default="llama3_8b")
     p.add_argument("--temperature", type=float, default=0.0, help="> 0: sampling head (reference default 0.1); 0 = greedy (BASELINE)")
     p.add_argument("--top-p", type=float, default=0.7)
-    p.add_argument("--bucket", type=int, default=256, help="residues per length bucket with --mixed-lengths")
+    p.add_argument("--bucket", type=int, default=256, help="residues per length bucket with --mixed-lengths --padded-encoder")
+    p.add_argument("--padded-encoder", action="store_true", help="A/B aid: the padded (length-bucketed) encoder of rounds 1-3 "
+                                                                 "instead of the token-packed one")
     p.add_argument("--no-c2", action="store_true", help="skip the batch-1 latency configuration (configs[1])")
     p.add_argument("--no-inflight", action="store_true", help="skip the two-batches-in-flight measurement (`two_in_flight`)")
     p.add_argument("--no-e2e", action="store_true", help="skip the strings-in -> ids-out measurement through model.generate (`e2e`)")
@@ -108,7 +110,11 @@ class Workload:
         self.sampler = (a.temperature, a.top_p, 1234) if a.temperature > 0 else None
         seqs = [synth.synth_protein(n, rank * B + i) for i, n in enumerate(lengths)]
         self.bucket_rows = None
-        if len(set(lengths)) > 1:     # configs[2]: length buckets of --bucket residues (padding never exceeds one bucket)
+        if not a.padded_encoder:      # token-packed encoder (default): the batch's tokens back to back, no padding, no buckets
+            from opus_pllm_amd.alphabet import batch_convert_packed
+            toks, cu = batch_convert_packed(seqs)
+            self.d_tok, self.d_len, self.bucket_rows = torch.from_numpy(toks).to(dev), [int(v) for v in cu], "packed"
+        elif len(set(lengths)) > 1:   # configs[2]: length buckets of --bucket residues (padding never exceeds one bucket)
             order = sorted(range(B), key=lambda i: lengths[i])
             groups = {}
             for i in order:
@@ -489,6 +495,7 @@ def main():
         log(f"building {a.model}: {synth.param_count(cfg) / 1e9:.2f} B synthetic parameters on {dev}")
         weights = DeviceWeights.synthetic(cfg, 0, dev)
         model = OpusLlamaForCausalLM(cfg, weights, dev)
+        model.packed_encoder = not a.padded_encoder
         torch.cuda.synchronize(dev)
         log(f"weights {weights.nbytes() / 1e9:.1f} GB resident")
         main_work = Workload(model, cfg, a, rank, B, lengths, dev)

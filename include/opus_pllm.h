@@ -116,6 +116,13 @@ int opus_tile_weight(const void *d_src, void *d_dst, int64_t N, int64_t K, void 
  * pooled fp32 [B, enc_dim] = mean over residues of representations[enc_layers]. */
 int opus_esm2_encode(opus_ctx *ctx, const int32_t *d_tokens, const int32_t *d_lens, int32_t B, int32_t T,
                      float *d_pooled, void *stream);
+/* The same rows on a TOKEN-PACKED batch (no padding: the reference pads to the longest protein of the batch,
+ * cstp_v3/modelling.py:44-46, and multiplies the padding): d_tokens int32 [cu[B]] = the proteins' tokens (<cls> seq <eos>) back
+ * to back, h_cu (HOST) int32 [B + 1] their row offsets (cu[0] = 0; 2 <= cu[b+1] - cu[b] <= max_enc_tokens;
+ * cu[B] <= max_batch * max_enc_tokens) -> pooled fp32 [B, enc_dim], the same values as opus_esm2_encode gives each protein
+ * (different GEMM tile boundaries: equal to the tolerance of DESIGN.md section 3, not bitwise).  Mixed lengths need no buckets.
+ * opus_esm2_last_hidden(ctx, out, 1, cu[B]) then returns the packed [cu[B], enc_dim] representations. */
+int opus_esm2_encode_packed(opus_ctx *ctx, const int32_t *d_tokens, const int32_t *h_cu, int32_t B, float *d_pooled, void *stream);
 /* Debug/parity tap: copy of representations[enc_layers] fp32 [B,T,enc_dim] of the last encode. */
 int opus_esm2_last_hidden(opus_ctx *ctx, float *d_out, int32_t B, int32_t T, void *stream);
 
@@ -221,6 +228,18 @@ int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const 
  * check (see Conventions; the results of the calls in between are invalid), OPUS_OK otherwise.  opus_generate_* make the same
  * check before they return.  No reference counterpart (torch raises asynchronously on device-side faults). */
 int opus_check_error(opus_ctx *ctx, void *stream);
+
+/* Row N1, `num_beams` (eval/run_opus_ddp.py:129,158 -> transformers GenerationMixin._beam_search).  The decoder runs B x K rows
+ * (row = b K + k) through opus_llama_prefill / opus_llama_decode_step; these two do the per-step work that touches O(K V) values or
+ * the KV cache, the caller keeps the O(K) bookkeeping of running / finished beams (opus-pllm_amd/beam.py, as the reference's
+ * Python does).
+ * opus_beam_topk: over the fp32 logits of this context's last step, scores fp32 [B, M] (descending; ties: lower index first)
+ *   and flat indices k * dec_vocab + token int32 [B, M] of the M best values of log_softmax(logits[b K + k]) + run_scores[b K + k]
+ *   (generation/utils.py _get_top_k_continuations; M = max(2, 1 + #eos) K <= 16).
+ * opus_kv_reorder: KV cache rows r <- rows d_src_rows[r] in every layer (Cache.reorder_cache(beam_idx)); R = rows of the last prefill. */
+int opus_beam_topk(opus_ctx *ctx, const float *d_run_scores, int32_t B, int32_t K, int32_t M, float *d_scores, int32_t *d_idx,
+                   void *stream);
+int opus_kv_reorder(opus_ctx *ctx, const int32_t *d_src_rows, int32_t R, void *stream);
 
 /* fp32 logits [B, dec_vocab] of the most recent prefill / decode step (device copy on `stream`): the payload of the
  * optional logits all-gather of SURVEY 8e (ids are what eval/run_opus_ddp.py:138 gathers). */

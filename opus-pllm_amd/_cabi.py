@@ -69,6 +69,7 @@ SIGNATURES = {
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_float, C.c_float, _P]),
     "opus_tile_weight": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "opus_esm2_encode": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "opus_esm2_encode_packed": (C.c_int, [_P, _P, C.POINTER(C.c_int32), C.c_int32, _P, _P]),
     "opus_esm2_last_hidden": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "opus_projector_forward": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     "opus_protein_projector": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
@@ -94,6 +95,8 @@ SIGNATURES = {
     "opus_timing_names": (C.c_int, [C.c_char_p, C.c_int32]),
     "opus_last_logits": (C.c_int, [_P, _P, C.c_int32, _P]),
     "opus_check_error": (C.c_int, [_P, _P]),
+    "opus_beam_topk": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "opus_kv_reorder": (C.c_int, [_P, _P, C.c_int32, _P]),
     "opus_set_stop_sequence": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
     "opus_debug_gemm_slabs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P]),
     "opus_debug_knob": (C.c_int, [_P, C.c_char_p, C.c_int32]),

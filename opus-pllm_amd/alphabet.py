@@ -80,3 +80,18 @@ def batch_convert(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
         toks[b, 1 + len(e)] = EOS_IDX
         lens[b] = len(e) + 2
     return toks, lens
+
+
+def batch_convert_packed(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+    """Token-packed form of `batch_convert` -> (tokens int32 [sum(len_b)], cu int32 [B + 1]): the rows <cls> residues <eos> back
+    to back WITHOUT padding and their offsets (cu[0] = 0); what opus_esm2_encode_packed consumes."""
+    enc = [encode_array(s) for s in seqs]
+    cu = np.zeros((len(enc) + 1,), dtype=np.int32)
+    for b, e in enumerate(enc):
+        cu[b + 1] = cu[b] + len(e) + 2
+    toks = np.empty((int(cu[-1]),), dtype=np.int32)
+    for b, e in enumerate(enc):
+        toks[cu[b]] = CLS_IDX
+        toks[cu[b] + 1:cu[b + 1] - 1] = e
+        toks[cu[b + 1] - 1] = EOS_IDX
+    return toks, cu

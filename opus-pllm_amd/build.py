@@ -18,7 +18,7 @@ SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libopus_pllm.so")
 LIB_BF16 = os.path.join(HERE, "lib", "libopus_pllm_bf16.so")      # the same sources with -DOPUS_BF16 (csrc/common.h)
-SOURCES = ["gemm.hip", "gemm_stream.hip", "norm.hip", "elementwise.hip", "attn_prefill.hip", "attn_decode.hip", "api.cpp"]
+SOURCES = ["gemm.hip", "gemm_stream.hip", "norm.hip", "elementwise.hip", "attn_prefill.hip", "attn_decode.hip", "beam.hip", "api.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
@@ -108,5 +108,37 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+LIB_ASAN = os.path.join(HERE, "lib", "libopus_pllm_asan.so")
+ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+def build_asan(verbose: bool = True) -> str:
+    """AddressSanitizer build of the HOST side of the C ABI ("optional ASan build of host C ABI"): api.cpp - context,
+    config checks, workspace carving, weight registry, launch sequencing, error strings - compiled with -fsanitize=address for
+    the host only (-fno-gpu-sanitize: GPU ASan is not available on this pool), linked with the ordinary kernel objects.  Load it
+    with LD_PRELOAD=<ASAN_RT> (tests/test_host.py::test_asan_host_build_runs_clean does, in a child process, CPU only)."""
+    build(verbose=False)
+    obj = os.path.join(OBJ, "api.cpp.asan.o")
+    src = os.path.join(SRC, "api.cpp")
+    if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), _deps_mtime()):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O1", "-g", "-fPIC", "-std=c++17", "-fsanitize=address", "-fno-gpu-sanitize",
+               "-shared-libsan", "-fno-omit-frame-pointer", "-x", "hip", "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (asan) failed on api.cpp:\n{r.stdout}\n{r.stderr}")
+    objs = [os.path.join(OBJ, s + ".o") for s in SOURCES if s != "api.cpp"] + [obj]
+    if not os.path.exists(LIB_ASAN) or any(os.path.getmtime(o) > os.path.getmtime(LIB_ASAN) for o in objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize",
+                            "-shared-libsan", "-o", LIB_ASAN] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (asan) failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB_ASAN} ({os.path.getsize(LIB_ASAN) / 1e6:.2f} MB); run under LD_PRELOAD={ASAN_RT}")
+    return LIB_ASAN
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--asan" in sys.argv:
+        build_asan()
+    else:
+        build(force="--force" in sys.argv)

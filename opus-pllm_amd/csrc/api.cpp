@@ -76,6 +76,8 @@ struct opus_ctx {
     char *ws = nullptr;
     size_t ws_bytes = 0;
     float *e_x, *e_hid, *p_pool_dummy, *e_part, *e_stat;
+    int32_t *e_cu, *e_pos;
+    std::vector<int32_t> h_cu;           // host copy of the packed encoder's row offsets (source of the async upload)
     half_t *e_xn, *e_qkv, *e_ctx, *e_h1;
     half_t *p_xn, *p_y, *p_z[2];
     float *d_x, *d_xl, *d_logits, *d_pval, *gemm_ws, *d_probs, *d_zpart, *d_spart, *d_part, *d_stat;
@@ -103,6 +105,7 @@ struct opus_ctx {
     int rq_done = 0;
     // one-shot request: fuse the ESM rotary into the next GEMM's epilogue (GemmParams::rope_*); rq_rope_done reports back
     const float *rq_rope_cs = nullptr;
+    const int32_t *rq_rope_pos = nullptr;
     int rq_rope_T = 0, rq_rope_cols = 0, rq_rope_qcols = 0, rq_rope_done = 0;
     float rq_rope_qscale = 1.0f;
     // one-shot requests for the next gemm(): route a narrow output through the wide kernel / leave raw k-part slabs
@@ -131,6 +134,8 @@ struct opus_ctx {
     // pipeline) allocates a separate BIG_PROJ_ROWS-row workspace (proj_big) and switches to it.
     int proj_rows = 0;
     char *proj_big = nullptr;
+    // beam search (opus_beam_topk / opus_kv_reorder): one layer's K and V cache rows while they are permuted (first use allocates)
+    half_t *kv_tmp = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -160,6 +165,8 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->e_h1 = k.take<half_t>(Me * Fe);
     c->e_part = k.take<float>(Me * (De / 64 + 1) * 2);              // (sum x, sum x^2) per row and 64-column slab (fused LayerNorm)
     c->e_stat = k.take<float>(Me * 2);                              // (mu, rstd) per row
+    c->e_cu = k.take<int32_t>((size_t)g.max_batch + 4);            // token-packed encoder: row offsets, row -> position table
+    c->e_pos = k.take<int32_t>(Me);
     const size_t B = g.max_batch, H = g.dec_dim, SW = (size_t)g.dec_dim * g.n_prot_tokens;
     const size_t PR = B;                         // (the two-stage pipeline's big workspace is allocated on first use: ensure_proj_rows)
     c->proj_rows = (int)PR;
@@ -329,6 +336,7 @@ extern "C" int opus_ctx_destroy(opus_ctx *c) {
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->ws) (void)hipFree(c->ws);
     if (c->proj_big) (void)hipFree(c->proj_big);
+    if (c->kv_tmp) (void)hipFree(c->kv_tmp);
     delete c;
     return OPUS_OK;
 }
@@ -488,9 +496,10 @@ static int gemm_any(opus_ctx *c, hipStream_t s, const half_t *A, const float *Af
     c->rq_done = 0;
     c->rq_xh = nullptr;                  // one-shot
     p.rope_cs = c->rq_rope_cs; p.rope_T = c->rq_rope_T; p.rope_cols = c->rq_rope_cols; p.rope_qcols = c->rq_rope_qcols;
-    p.rope_qscale = c->rq_rope_qscale; p.rope_done = &c->rq_rope_done;
+    p.rope_qscale = c->rq_rope_qscale; p.rope_done = &c->rq_rope_done; p.rope_pos = c->rq_rope_pos;
     c->rq_rope_done = 0;
     c->rq_rope_cs = nullptr;             // one-shot
+    c->rq_rope_pos = nullptr;
     p.row_ssq = nullptr; p.row_nblk = 0;
     if (c->use_row_scale) { p.row_ssq = c->d_ssq; p.row_nblk = c->ssq_nblk; p.norm_eps = c->row_eps; c->use_row_scale = false; }
     c->rq_ks = 1;
@@ -593,19 +602,20 @@ extern "C" int opus_tile_weight(const void *d_src, void *d_dst, int64_t N, int64
 }
 
 // ------------------------------------------------------------------------------------------------ encoder
-extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int32_t *d_lens, int32_t B, int32_t T,
-                                float *d_pooled, void *stream) {
-    OPC(need_ready(c));
-    if (!d_tokens || !d_lens || !d_pooled) return fail(OPUS_EBADARG, "esm2_encode: null pointer");
+// The encoder over M token rows.  Padded form (d_cu == nullptr): M = B T rows, row b t at b T + t, keys >= lens[b] masked.
+// Token-packed form (SURVEY 5 "length-bucketed / varlen batches"): the rows are the proteins' tokens back to back, d_cu[B + 1] their
+// offsets, T the longest protein - the GEMMs multiply no padding and a batch of mixed lengths is ONE set of large launches
+// instead of one per length bucket; positions come from a row -> position table (written by the embedding kernel), the attention
+// takes its rows from cu.
+static int esm2_encode_rows(opus_ctx *c, hipStream_t s, const int32_t *d_tokens, const int32_t *d_lens, const int32_t *d_cu, int B, int T,
+                            int M, float *d_pooled) {
     const opus_config &g = c->cfg;
-    if (B < 1 || B > g.max_batch || T < 3 || T > g.max_enc_tokens)
-        return fail(OPUS_ESHAPE, "esm2_encode: B=%d T=%d exceed capacity (%d, %d)", B, T, g.max_batch, g.max_enc_tokens);
-    hipStream_t s = (hipStream_t)stream;
     c->phase = PH_ENCODE;
     const int D = g.enc_dim, F = g.enc_ffn, nh = g.enc_heads, hd = D / nh;
-    const int M = B * T;
+    const bool packed = d_cu != nullptr;
     HIPC(hipMemsetAsync(c->d_cnt, 0, HANDOFF_ERR * sizeof(int32_t), s));       // hand-off words start from zero on every call
-    KL(KC_OTHER, 4.0 * M * D, launch_esm_embed(d_tokens, c->enc_emb, B, T, D, c->e_x, s));
+    if (packed) KL(KC_OTHER, 4.0 * M * D, launch_esm_embed_packed(d_tokens, c->enc_emb, d_cu, B, T, D, c->e_x, c->e_pos, s));
+    else KL(KC_OTHER, 4.0 * M * D, launch_esm_embed(d_tokens, c->enc_emb, B, T, D, c->e_x, s));
     // Pre-LN blocks with the LayerNorm fused around the big tiled GEMM (GemmParams::ln_*): the epilogue that writes
     // the residual stream (wo, fc2) also leaves fp16(x) and per-row partial sums, a small kernel turns those into (mu, rstd),
     // and the consuming projection (fc1, the next layer's QKV) runs on fp16(x) as it stands and applies
@@ -621,6 +631,9 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
         KL(KC_NORM, 8.0 * M * (D / 64) + 8.0 * M, launch_ln_finalize(c->e_part, M, D / 64, D, g.enc_ln_eps, 0, c->e_stat, s));
         return OPUS_OK;
     };
+    double attn_flops = 0.0;                       // 4 T_b^2 D per protein
+    if (packed) for (int b = 0; b < B; ++b) { const double t = c->h_cu[b + 1] - c->h_cu[b]; attn_flops += 4.0 * t * t * D; }
+    else attn_flops = 4.0 * B * (double)T * T * D;
     for (int l = 0; l < g.enc_layers; ++l) {
         const EncLayer &L = c->enc[l];
         if (have_stat && qkv_pp) { c->rq_ln_stat = c->e_stat; c->rq_ln_colsum = L.sqkv; }
@@ -628,20 +641,23 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
         // q <- rotary(q * hd^-0.5), k <- rotary(k): in the projection's epilogue when the big tiled kernel takes it (head_dim 64),
         // else by the stand-alone kernel on the stored projection (same arithmetic)
         if (hd == 64) {
-            c->rq_rope_cs = c->cs_enc; c->rq_rope_T = T; c->rq_rope_cols = 2 * D; c->rq_rope_qcols = D;
+            c->rq_rope_cs = c->cs_enc; c->rq_rope_T = packed ? g.max_enc_tokens : T; c->rq_rope_cols = 2 * D; c->rq_rope_qcols = D;
             c->rq_rope_qscale = 1.0f / sqrtf((float)hd);
+            c->rq_rope_pos = packed ? c->e_pos : nullptr;
         }
         OPC(gemm(c, s, c->e_xn, D, L.wqkv, M, 3 * D, D, L.bqkv, EPI_NONE, nullptr, c->e_qkv, 3 * D, 0));
-        if (!c->rq_rope_done)
-            KL(KC_OTHER, 8.0 * M * D, launch_esm_rope(c->e_qkv, c->cs_enc, B, T, nh, hd, 1.0f / sqrtf((float)hd), s));
+        if (!c->rq_rope_done) {
+            if (packed) KL(KC_OTHER, 8.0 * M * D, launch_esm_rope(c->e_qkv, c->cs_enc, 1, M, nh, hd, 1.0f / sqrtf((float)hd), s, c->e_pos));
+            else KL(KC_OTHER, 8.0 * M * D, launch_esm_rope(c->e_qkv, c->cs_enc, B, T, nh, hd, 1.0f / sqrtf((float)hd), s));
+        }
         AttnParams a;
         a.Q = c->e_qkv; a.K = c->e_qkv + D; a.V = c->e_qkv + 2 * D;
-        a.q_sb = a.k_sb = a.v_sb = (int64_t)T * 3 * D;
+        a.q_sb = a.k_sb = a.v_sb = packed ? 0 : (int64_t)T * 3 * D;
         a.q_st = a.k_st = a.v_st = 3 * D;
-        a.O = c->e_ctx; a.o_sb = (int64_t)T * D; a.o_st = D;
-        a.kstart = nullptr; a.kend = d_lens;
+        a.O = c->e_ctx; a.o_sb = packed ? 0 : (int64_t)T * D; a.o_st = D;
+        a.kstart = nullptr; a.kend = packed ? nullptr : d_lens; a.cu = d_cu;
         a.B = B; a.T = T; a.heads = nh; a.group = 1; a.head_dim = hd; a.causal = 0; a.scale = 1.0f;
-        KLF(KC_ATTN_PREFILL, 8.0 * M * D, 4.0 * B * (double)T * T * D, launch_attn_prefill(a, s));
+        KLF(KC_ATTN_PREFILL, 8.0 * M * D, attn_flops, launch_attn_prefill(a, s));
         if (fc1_pp) { c->rq_ln_part = c->e_part; c->rq_ln_xh = c->e_xn; }
         OPC(gemm(c, s, c->e_ctx, D, L.wo, M, D, D, L.bo, EPI_NONE, c->e_x, c->e_x, D, 1));
         have_stat = c->rq_ln_done != 0;
@@ -654,13 +670,46 @@ extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int3
         if (have_stat) OPC(finalize());
     }
     KL(KC_NORM, 8.0 * M * D, launch_layernorm(c->e_x, c->enc_lnfw, c->enc_lnfb, g.enc_ln_eps, M, D, nullptr, c->e_hid, s));
-    KL(KC_OTHER, 4.0 * M * D, launch_masked_mean(c->e_hid, d_lens, B, T, D, d_pooled, s));
+    if (packed) KL(KC_OTHER, 4.0 * M * D, launch_masked_mean_packed(c->e_hid, d_cu, B, D, d_pooled, s));
+    else KL(KC_OTHER, 4.0 * M * D, launch_masked_mean(c->e_hid, d_lens, B, T, D, d_pooled, s));
     return OPUS_OK;
+}
+
+extern "C" int opus_esm2_encode(opus_ctx *c, const int32_t *d_tokens, const int32_t *d_lens, int32_t B, int32_t T,
+                                float *d_pooled, void *stream) {
+    OPC(need_ready(c));
+    if (!d_tokens || !d_lens || !d_pooled) return fail(OPUS_EBADARG, "esm2_encode: null pointer");
+    const opus_config &g = c->cfg;
+    if (B < 1 || B > g.max_batch || T < 3 || T > g.max_enc_tokens)
+        return fail(OPUS_ESHAPE, "esm2_encode: B=%d T=%d exceed capacity (%d, %d)", B, T, g.max_batch, g.max_enc_tokens);
+    return esm2_encode_rows(c, (hipStream_t)stream, d_tokens, d_lens, nullptr, B, T, B * T, d_pooled);
+}
+
+extern "C" int opus_esm2_encode_packed(opus_ctx *c, const int32_t *d_tokens, const int32_t *h_cu, int32_t B, float *d_pooled,
+                                       void *stream) {
+    OPC(need_ready(c));
+    if (!d_tokens || !h_cu || !d_pooled) return fail(OPUS_EBADARG, "esm2_encode_packed: null pointer");
+    const opus_config &g = c->cfg;
+    if (B < 1 || B > g.max_batch) return fail(OPUS_ESHAPE, "esm2_encode_packed: B=%d exceeds max_batch=%d", B, g.max_batch);
+    if (h_cu[0] != 0) return fail(OPUS_EBADARG, "esm2_encode_packed: cu[0] must be 0");
+    int Tmax = 0;
+    for (int b = 0; b < B; ++b) {
+        const int t = h_cu[b + 1] - h_cu[b];
+        if (t < 2 || t > g.max_enc_tokens)     // (<cls> <eos> at least)
+            return fail(OPUS_ESHAPE, "esm2_encode_packed: protein %d has %d tokens (2 .. max_enc_tokens=%d)", b, t, g.max_enc_tokens);
+        Tmax = t > Tmax ? t : Tmax;
+    }
+    const int64_t M = h_cu[B];
+    if (M > (int64_t)g.max_batch * g.max_enc_tokens) return fail(OPUS_ESHAPE, "esm2_encode_packed: %lld tokens exceed the workspace", (long long)M);
+    hipStream_t s = (hipStream_t)stream;
+    c->h_cu.assign(h_cu, h_cu + B + 1);                              // (host copy: per-protein FLOP accounting of the timing records)
+    HIPC(launch_upload_i32(h_cu, B + 1, c->e_cu, s));                 // through the kernel arguments: no host buffer outlives the call
+    return esm2_encode_rows(c, s, d_tokens, nullptr, c->e_cu, B, Tmax, (int)M, d_pooled);
 }
 
 extern "C" int opus_esm2_last_hidden(opus_ctx *c, float *d_out, int32_t B, int32_t T, void *stream) {
     if (!c || !d_out) return fail(OPUS_EBADARG, "null pointer");
-    if (B < 1 || B > c->cfg.max_batch || T < 1 || T > c->cfg.max_enc_tokens) return fail(OPUS_ESHAPE, "B/T out of range");
+    if (B < 1 || T < 1 || (int64_t)B * T > (int64_t)c->cfg.max_batch * c->cfg.max_enc_tokens) return fail(OPUS_ESHAPE, "B/T out of range");   // (B = 1, T = all tokens: the packed form)
     HIPC(hipMemcpyAsync(d_out, c->e_hid, (size_t)B * T * c->cfg.enc_dim * sizeof(float), hipMemcpyDeviceToDevice,
                         (hipStream_t)stream));
     return OPUS_OK;
@@ -1333,6 +1382,46 @@ extern "C" int opus_debug_gemm_slabs(opus_ctx *c, const void *A, const void *W, 
     *ks = c->rq_ks;
     if (c->rq_ks > 1 && d_slabs)
         HIPC(hipMemcpyAsync(d_slabs, c->gemm_ws, (size_t)c->rq_ks * M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return OPUS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ beam search support
+// The best M continuations of every batch row over its K beams' last logits (this context's most recent prefill / decode step
+// on B K rows, row = b K + k): transformers generation/utils.py _beam_search step b-c - log_softmax in fp32, + running beam
+// scores, torch.topk over the flattened [K V] - scores fp32 [B, M] descending and flat indices k V + token int32 [B, M].
+extern "C" int opus_beam_topk(opus_ctx *c, const float *d_run_scores, int32_t B, int32_t K, int32_t M, float *d_scores,
+                              int32_t *d_idx, void *stream) {
+    if (!c || !d_run_scores || !d_scores || !d_idx) return fail(OPUS_EBADARG, "beam_topk: null pointer");
+    if (!c->prefilled) return fail(OPUS_ESTATE, "beam_topk before prefill");
+    if (B < 1 || K < 1 || B * K != c->cur_B) return fail(OPUS_ESHAPE, "beam_topk: B=%d x K=%d rows, the last step had %d", B, K, c->cur_B);
+    if (M < 1 || M > 16) return fail(OPUS_ESHAPE, "beam_topk: 1 <= M <= 16 candidates per row (got %d)", M);
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    c->phase = PH_DECODE;
+    KL(KC_OTHER, 12.0 * c->cur_B * c->cfg.dec_vocab,
+       launch_beam_topk(c->d_logits, d_run_scores, B, K, c->cfg.dec_vocab, M, c->d_zpart, d_scores, d_idx, s));
+    return OPUS_OK;
+}
+
+// KV cache rows r <- rows src[r] for every layer (Cache.reorder_cache(beam_idx) of the reference's stack: the beams that
+// survive a step continue from their parents' caches).  R = the rows of the last prefill.  Two passes per layer through a
+// one-layer scratch (a permutation cannot be applied in place row by row).
+extern "C" int opus_kv_reorder(opus_ctx *c, const int32_t *d_src_rows, int32_t R, void *stream) {
+    if (!c || !d_src_rows) return fail(OPUS_EBADARG, "kv_reorder: null pointer");
+    if (!c->prefilled || R != c->cur_B) return fail(OPUS_ESHAPE, "kv_reorder: R=%d but the last prefill had %d rows", R, c->prefilled ? c->cur_B : 0);
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const opus_config &g = c->cfg;
+    const size_t row = (size_t)c->cache_sb, layer = row * g.max_batch;
+    if (!c->kv_tmp) HIPC(hipMalloc((void **)&c->kv_tmp, 2 * layer * sizeof(half_t)));
+    c->phase = PH_DECODE;
+    for (int l = 0; l < g.dec_layers; ++l) {
+        half_t *kc = c->kc + l * c->cache_sl, *vc = c->vc + l * c->cache_sl;
+        KL(KC_OTHER, 8.0 * R * row, launch_kv_gather_rows(kc, c->kv_tmp, d_src_rows, R, (int64_t)row, s));
+        HIPC(launch_kv_gather_rows(vc, c->kv_tmp + layer, d_src_rows, R, (int64_t)row, s));
+        HIPC(hipMemcpyAsync(kc, c->kv_tmp, (size_t)R * row * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+        HIPC(hipMemcpyAsync(vc, c->kv_tmp + layer, (size_t)R * row * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+    }
     return OPUS_OK;
 }
 

@@ -87,19 +87,29 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     if (bh >= p.B * p.heads) return;
     const int b = bh / p.heads, h = bh % p.heads, hk = h / p.group;
     const int q0 = (slot % nqb) * QB, qw = q0 + wave * QW;
-    const int kstart = p.kstart ? p.kstart[b] : 0;
-    const int kend = p.kend ? p.kend[b] : p.T;
+    // token-packed batch (AttnParams::cu): this row's tokens are rows cu[b] .. cu[b + 1] - 1 of Q / K / V / O, all of them
+    // visible keys; query blocks past the row's last token (the grid is sized by the longest row) leave at once
+    int T = p.T;
+    int64_t qb_off = (int64_t)b * p.q_sb, kb_off = (int64_t)b * p.k_sb, vb_off = (int64_t)b * p.v_sb, ob_off = (int64_t)b * p.o_sb;
+    if (p.cu) {
+        const int r0 = p.cu[b];
+        T = p.cu[b + 1] - r0;
+        if (q0 >= T) return;                                          // (uniform, before any barrier)
+        qb_off = (int64_t)r0 * p.q_st; kb_off = (int64_t)r0 * p.k_st; vb_off = (int64_t)r0 * p.v_st; ob_off = (int64_t)r0 * p.o_st;
+    }
+    const int kstart = (p.kstart && !p.cu) ? p.kstart[b] : 0;
+    const int kend = (p.kend && !p.cu) ? p.kend[b] : T;
 
-    const half_t *Qb = p.Q + (int64_t)b * p.q_sb + (int64_t)h * HD;
-    const half_t *Kb = p.K + (int64_t)b * p.k_sb + (int64_t)hk * HD;
-    const half_t *Vb = p.V + (int64_t)b * p.v_sb + (int64_t)hk * HD;
+    const half_t *Qb = p.Q + qb_off + (int64_t)h * HD;
+    const half_t *Kb = p.K + kb_off + (int64_t)hk * HD;
+    const half_t *Vb = p.V + vb_off + (int64_t)hk * HD;
 
     // Q^T fragments (B operand): column li = query, k = 32 s + 8 g + e
     h8 qf[QT][KS];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         int qr = qw + 16 * t + li;
-        qr = qr < p.T ? qr : p.T - 1;
+        qr = qr < T ? qr : T - 1;
         const half_t *src = Qb + (int64_t)qr * p.q_st;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -120,11 +130,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     int k_lo = kstart / KB * KB;
     int k_hi = kend;
     if (CAUSAL) {
-        const int last_q = (q0 + QB - 1 < p.T - 1 ? q0 + QB - 1 : p.T - 1);
+        const int last_q = (q0 + QB - 1 < T - 1 ? q0 + QB - 1 : T - 1);
         k_hi = k_hi < last_q + 1 ? k_hi : last_q + 1;
     }
     const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
-    const bool wave_live = qw < p.T;                  // waves past the last query only help with the tile staging
+    const bool wave_live = qw < T;                  // waves past the last query only help with the tile staging
 
     // K/V tiles: global -> registers one tile ahead of the LDS copy
     constexpr int KL = KB * CH / 256;            // 16-B pieces of K per thread and tile
@@ -135,8 +145,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     // through buffer descriptors that end with the batch row's last key: rows >= T of the last tile read as zeros without a
     // clamp, and a tile's addresses are the thread's fixed byte offsets plus one wave-uniform term (no 64-bit address
     // arithmetic per tile: that was ~30 VALU instructions of every tile, 8 of them quarter-rate multiplies)
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (int)(((int64_t)(p.T - 1) * p.k_st + HD) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (int)(((int64_t)(p.T - 1) * p.v_st + HD) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (int)(((int64_t)(T - 1) * p.k_st + HD) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (int)(((int64_t)(T - 1) * p.v_st + HD) * 2), 0x00020000);
     int koff[KL], voff[VL];
 #pragma unroll
     for (int u = 0; u < KL; ++u) {
@@ -316,9 +326,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const int qi = qw + 16 * t + li;
-        if (qi >= p.T) continue;
+        if (qi >= T) continue;
         const float inv = l > 0.f ? 1.0f / l : 0.f;
-        half_t *dst = p.O + (int64_t)b * p.o_sb + (int64_t)qi * p.o_st + (int64_t)h * HD;
+        half_t *dst = p.O + ob_off + (int64_t)qi * p.o_st + (int64_t)h * HD;
 #pragma unroll
         for (int n = 0; n < NO; ++n)
             *reinterpret_cast<h4 *>(dst + 16 * n + 4 * g) =

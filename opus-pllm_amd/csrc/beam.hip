@@ -1,0 +1,124 @@
+// Beam search support (row N1 of SURVEY 8f: the `num_beams` pass-through of eval/run_opus_ddp.py:129,158 -> transformers
+// GenerationMixin._beam_search).  The decoder runs B x K rows (row = b K + k) through the ordinary prefill / decode step; per
+// step the device does the two things that touch O(K V) or the KV cache,
+//   beam_lse / beam_topk   log_softmax of the K beams' logits in fp32, + the beams' running scores, and the best M of the K V
+//                          continuations of each batch row (generation/utils.py _get_top_k_continuations: torch.topk over
+//                          the flattened [K V] accumulated log-probabilities; M = max(2, 1 + #eos) K),
+//   kv_gather_rows         the cache rows of the surviving beams (Cache.reorder_cache / index_select(0, beam_idx)),
+// and the host (opus-pllm_amd/beam.py) keeps the O(K) bookkeeping of the finished / running beams, as the reference's Python does.
+#include "common.h"
+
+namespace opus {
+
+// lse[row] = log sum_v exp(logits[row][v]) (max-shifted, fp32), one workgroup per decoder row
+__global__ __launch_bounds__(256) void beam_lse_kernel(const float *__restrict__ logits, int V, float *__restrict__ lse) {
+    __shared__ float red[256];
+    const float *row = logits + (int64_t)blockIdx.x * V;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, row[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) s += expf(row[i] - m);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {            // fixed tree: bitwise reproducible
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) lse[blockIdx.x] = m + logf(red[0]);
+}
+
+constexpr int BEAM_MAXM = 16;     // candidates kept per batch row and step
+
+// The best M of the K V continuations of batch row b: score(k, v) = (logits[b K + k][v] - lse[b K + k]) + run[b K + k], sorted
+// by score descending, ties by the lower flat index k V + v.  One workgroup per batch row: every thread keeps the best M of its
+// strided share in registers, then M rounds of a block-wide arg-max over the heads of the threads' sorted lists.
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float *__restrict__ logits, const float *__restrict__ lse,
+                                                        const float *__restrict__ run, int K, int V, int M,
+                                                        float *__restrict__ out_s, int32_t *__restrict__ out_i) {
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    __shared__ int s_who[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float bs[BEAM_MAXM];
+    int bi[BEAM_MAXM];
+#pragma unroll
+    for (int j = 0; j < BEAM_MAXM; ++j) { bs[j] = -INFINITY; bi[j] = 0x7fffffff; }
+    for (int k = 0; k < K; ++k) {
+        const float *row = logits + (int64_t)(b * K + k) * V;
+        const float off = lse[b * K + k], add = run[b * K + k];
+        for (int v = tid; v < V; v += 256) {
+            const float sc = (row[v] - off) + add;
+            const int id = k * V + v;
+            if (sc > bs[BEAM_MAXM - 1] || (sc == bs[BEAM_MAXM - 1] && id < bi[BEAM_MAXM - 1])) {
+                // insertion into the sorted list (static indices: the list stays in registers)
+                float cs = sc;
+                int ci = id;
+#pragma unroll
+                for (int j = 0; j < BEAM_MAXM; ++j) {
+                    const bool better = cs > bs[j] || (cs == bs[j] && ci < bi[j]);
+                    const float ts = better ? bs[j] : cs;
+                    const int ti = better ? bi[j] : ci;
+                    bs[j] = better ? cs : bs[j];
+                    bi[j] = better ? ci : bi[j];
+                    cs = ts;
+                    ci = ti;
+                }
+            }
+        }
+    }
+    int head = 0;                                    // this thread's next unused entry
+    for (int r = 0; r < M; ++r) {
+        float hv = -INFINITY;
+        int hi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < BEAM_MAXM; ++j)
+            if (j == head) { hv = bs[j]; hi = bi[j]; }
+        s_v[tid] = hv; s_i[tid] = hi; s_who[tid] = tid;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float v = s_v[tid + o];
+                const int i = s_i[tid + o];
+                if (v > s_v[tid] || (v == s_v[tid] && i < s_i[tid])) { s_v[tid] = v; s_i[tid] = i; s_who[tid] = s_who[tid + o]; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { out_s[b * M + r] = s_v[0]; out_i[b * M + r] = s_i[0]; }
+        if (s_who[0] == tid) ++head;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_beam_topk(const float *logits, const float *run, int B, int K, int V, int M, float *lse, float *out_s,
+                            int32_t *out_i, hipStream_t s) {
+    if (M < 1 || M > BEAM_MAXM || K < 1 || (int64_t)K * V >= 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(beam_lse_kernel, dim3(B * K), dim3(256), 0, s, logits, V, lse);
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(256), 0, s, logits, lse, run, K, V, M, out_s, out_i);
+    return hipGetLastError();
+}
+
+// dst[r][:] = src[idx[r]][:] for R rows of `row_halfs` fp16 values (16-byte pieces; one layer's K or V cache rows)
+__global__ __launch_bounds__(256) void kv_gather_rows_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst,
+                                                             const int32_t *__restrict__ idx, int64_t row_halfs) {
+    const int r = blockIdx.y;
+    const h8 *s = reinterpret_cast<const h8 *>(src + (int64_t)idx[r] * row_halfs);
+    h8 *d = reinterpret_cast<h8 *>(dst + (int64_t)r * row_halfs);
+    const int64_t n8 = row_halfs >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+hipError_t launch_kv_gather_rows(const half_t *src, half_t *dst, const int32_t *idx, int R, int64_t row_halfs, hipStream_t s) {
+    if (row_halfs & 7) return hipErrorInvalidValue;
+    const int gx = (int)((row_halfs >> 3) + 255) / 256;
+    hipLaunchKernelGGL(kv_gather_rows_kernel, dim3(gx > 64 ? 64 : gx, R), dim3(256), 0, s, src, dst, idx, row_halfs);
+    return hipGetLastError();
+}
+
+}  // namespace opus

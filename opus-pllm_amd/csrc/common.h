@@ -146,6 +146,7 @@ struct GemmParams {
     // (cos, sin) table - after the usual rounding to fp16, columns < rope_qcols being scaled by rope_qscale first: the same
     // arithmetic as esm_rope_kernel on the stored projection.  *rope_done = 1 when the launch applied it.
     const float *rope_cs = nullptr;
+    const int32_t *rope_pos = nullptr;      // token-packed batches: position of every row (instead of row % rope_T)
     int rope_T = 0, rope_cols = 0, rope_qcols = 0;
     float rope_qscale = 1.0f;
     int *rope_done = nullptr;
@@ -189,6 +190,10 @@ struct AttnParams {
     const int32_t *kend;    // [B] or nullptr (= T)
     int B, T, heads, group, head_dim, causal;
     float scale;
+    // Token-packed ("varlen") batches: cu[B + 1] row offsets into Q / K / V / O, whose rows are the batch rows' tokens back to
+    // back with no padding (q_sb / k_sb / v_sb / o_sb unused).  Row b has cu[b + 1] - cu[b] tokens, all of them visible keys
+    // (kstart / kend unused); T = the longest row (sizes the grid).
+    const int32_t *cu = nullptr;
 };
 
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass);
@@ -256,11 +261,15 @@ hipError_t launch_l2norm(const float *x, int64_t rows, int D, half_t *out, hipSt
 hipError_t launch_f2h(const float *x, int64_t n, half_t *out, hipStream_t s);
 hipError_t launch_masked_mean(const float *h, const int32_t *lens, int B, int T, int D, float *out,
                               hipStream_t s);
+// token-packed forms (cu[B + 1] row offsets; Tmax = the longest row): embedding, pooling, and the row -> position table
+hipError_t launch_masked_mean_packed(const float *h, const int32_t *cu, int B, int D, float *out, hipStream_t s);
+hipError_t launch_esm_embed_packed(const int32_t *tok, const half_t *emb, const int32_t *cu, int B, int Tmax, int D, float *x,
+                                   int32_t *pos, hipStream_t s);
 
 // elementwise.hip
 hipError_t launch_esm_embed(const int32_t *tok, const half_t *emb, int B, int T, int D, float *x, hipStream_t s);
 hipError_t launch_esm_rope(half_t *qkv, const float *cs, int B, int T, int heads, int hd, float qscale,
-                           hipStream_t s);
+                           hipStream_t s, const int32_t *pos = nullptr);   // pos: per-row positions (packed batches; B * T rows)
 hipError_t launch_dec_rope_cache(half_t *qkv, const float *cs, const int32_t *kstart, int B, int T, int nh,
                                  int nkv, int hd, half_t *kc, half_t *vc, int64_t cache_sb, int64_t cache_sh,
                                  hipStream_t s);
@@ -294,6 +303,11 @@ hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, const int3
                               int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
                               int32_t *next_tok, int32_t *n_unfinished, const int32_t *stop, int n_stop, hipStream_t s);
 hipError_t launch_step_advance(int32_t *step, hipStream_t s);
+// beam.hip: best M of the K V continuations per batch row (log_softmax + running scores), cache rows of the surviving beams
+hipError_t launch_beam_topk(const float *logits, const float *run, int B, int K, int V, int M, float *lse, float *out_s,
+                            int32_t *out_i, hipStream_t s);
+hipError_t launch_kv_gather_rows(const half_t *src, half_t *dst, const int32_t *idx, int R, int64_t row_halfs, hipStream_t s);
+hipError_t launch_upload_i32(const int32_t *h, int n, int32_t *dst, hipStream_t s);   // host ints -> device through kernel arguments
 hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kstart, hipStream_t s);
 
 // attn_decode.hip : rope(q,k at the new slot) + cache append + single-query attention

@@ -6,11 +6,20 @@ namespace opus {
 // ------------------------------------------------------------------------------ ESM-2 embedding (E1)
 // x[b,t,:] = emb[tok] * 0.88 / (1 - n_mask_b / n_nonpad_b), <mask> rows and <pad> rows zeroed
 // (token-dropout rescale of fair_esm ESM2.forward; modeling_esm.py:252-268).
+// Token-packed form (cu != nullptr): row b's tokens are tok[cu[b] .. cu[b + 1]) and its output rows x[cu[b] ..]; the kernel also
+// writes the row -> position table pos[cu[b] + t] = t that the rotary of the packed encoder reads.
 __global__ __launch_bounds__(256) void esm_embed_kernel(const int32_t *__restrict__ tok, const half_t *__restrict__ emb,
-                                                        int T, int D, float *__restrict__ x) {
+                                                        int T, int D, float *__restrict__ x, const int32_t *__restrict__ cu,
+                                                        int32_t *__restrict__ pos) {
     __shared__ int s_cnt[2];
     const int b = blockIdx.y;
-    const int32_t *row = tok + (int64_t)b * T;
+    int64_t r0 = (int64_t)b * T;
+    if (cu) {
+        r0 = cu[b];
+        T = cu[b + 1] - cu[b];
+        if ((int)blockIdx.x * 16 >= T) return;               // (uniform: before any barrier)
+    }
+    const int32_t *row = tok + r0;
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     int nm = 0, nv = 0;
@@ -38,14 +47,21 @@ __global__ __launch_bounds__(256) void esm_embed_kernel(const int32_t *__restric
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (float)e[j] * scale;
         }
-        float4 *dst = reinterpret_cast<float4 *>(x + ((int64_t)b * T + t) * D + c * 8);
+        float4 *dst = reinterpret_cast<float4 *>(x + (r0 + t) * D + c * 8);
         dst[0] = make_float4(o[0], o[1], o[2], o[3]);
         dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        if (pos && c == 0) pos[r0 + t] = t;
     }
 }
 
 hipError_t launch_esm_embed(const int32_t *tok, const half_t *emb, int B, int T, int D, float *x, hipStream_t s) {
-    hipLaunchKernelGGL(esm_embed_kernel, dim3(cdiv(T, 16), B), dim3(256), 0, s, tok, emb, T, D, x);
+    hipLaunchKernelGGL(esm_embed_kernel, dim3(cdiv(T, 16), B), dim3(256), 0, s, tok, emb, T, D, x, nullptr, nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_esm_embed_packed(const int32_t *tok, const half_t *emb, const int32_t *cu, int B, int Tmax, int D, float *x,
+                                   int32_t *pos, hipStream_t s) {
+    if (!cu || !pos) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(esm_embed_kernel, dim3(cdiv(Tmax, 16), B), dim3(256), 0, s, tok, emb, Tmax, D, x, cu, pos);
     return hipGetLastError();
 }
 
@@ -72,7 +88,7 @@ __device__ __forceinline__ void rope8(half_t *base, int half, const float *cs, f
 // ESM-2 (E2): q <- rotary(q * hd^-0.5), k <- rotary(k), positions 0..T-1, in place on the fused
 // [B*T, 3D] projection output (query scaled BEFORE the rotation, modeling_esm.py:374).
 __global__ __launch_bounds__(256) void esm_rope_kernel(half_t *__restrict__ qkv, const float *__restrict__ cs, int T,
-                                                       int heads, int hd, float qscale, int64_t total) {
+                                                       int heads, int hd, float qscale, int64_t total, const int32_t *__restrict__ pos) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int half = hd >> 1, vph = half >> 3;            // 8-wide vectors per half head
@@ -81,16 +97,16 @@ __global__ __launch_bounds__(256) void esm_rope_kernel(half_t *__restrict__ qkv,
     const int h = (int)(r % heads); r /= heads;
     const int which = (int)(r & 1);                        // 0 = q, 1 = k
     const int64_t row = r >> 1;
-    const int t = (int)(row % T);
+    const int t = pos ? pos[row] : (int)(row % T);          // (token-packed batches: the row's position comes from the table)
     const int D = heads * hd;
     half_t *base = qkv + row * (3 * (int64_t)D) + which * D + h * hd + v * 8;
     rope8(base, half, cs + ((int64_t)t * half + v * 8) * 2, which == 0 ? qscale : 1.0f);
 }
 
-hipError_t launch_esm_rope(half_t *qkv, const float *cs, int B, int T, int heads, int hd, float qscale, hipStream_t s) {
+hipError_t launch_esm_rope(half_t *qkv, const float *cs, int B, int T, int heads, int hd, float qscale, hipStream_t s, const int32_t *pos) {
     if (hd & 15) return hipErrorInvalidValue;
     const int64_t total = (int64_t)B * T * 2 * heads * (hd >> 4);
-    hipLaunchKernelGGL(esm_rope_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, qkv, cs, T, heads, hd, qscale, total);
+    hipLaunchKernelGGL(esm_rope_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, qkv, cs, T, heads, hd, qscale, total, pos);
     return hipGetLastError();
 }
 
@@ -725,6 +741,22 @@ hipError_t launch_sample_select(const float *logits, int B, int V, float tempera
 __global__ void step_advance_kernel(int32_t *step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
 }
+// A few host integers to device memory THROUGH THE KERNEL ARGUMENTS (<= 256 per launch): no host buffer has to outlive the call,
+// nothing synchronises, and the launch is capturable (the packed encoder's row offsets: B + 1 values per call).
+struct I32Chunk { int32_t v[256]; };
+__global__ __launch_bounds__(256) void upload_i32_kernel(I32Chunk c, int n, int32_t *__restrict__ dst) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+hipError_t launch_upload_i32(const int32_t *h, int n, int32_t *dst, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        I32Chunk c;
+        const int m = n - i0 < 256 ? n - i0 : 256;
+        for (int i = 0; i < 256; ++i) c.v[i] = i < m ? h[i0 + i] : 0;
+        hipLaunchKernelGGL(upload_i32_kernel, dim3(1), dim3(256), 0, s, c, m, dst + i0);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_step_advance(int32_t *step, hipStream_t s) {
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step);
     return hipGetLastError();

@@ -1352,11 +1352,28 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams &p, f4 (&acc)[8][4]
     // fetched a stage ahead through the (unused) residual slots.
     constexpr bool ROPE_OK = EPI == EPI_NONE && NO == 64 && NR >= 4;
     const bool rope_on = ROPE_OK && p.rope_cs != nullptr && !p.out_f32 && nw0 < p.rope_cols;   // wave-uniform
-    auto load_cs = [&](int i, float4 (&rr)[NR]) {
+    // position of this lane's row (row lane / 4 of each of the 8 row tiles): row % rope_T, or - token-packed batches - from
+    // the row -> position table, all 8 requested in one batch at the head of the rotary loop (inside load_cs each would be a
+    // dependent round trip in front of the (cos, sin) fetch of its stage)
+    auto rope_positions = [&](int (&rpos)[8]) {
         if constexpr (ROPE_OK) {
-            const int mb = m0 + wr * 128 + i * 16;
-            int t = __builtin_amdgcn_readfirstlane(mb % p.rope_T) + (lane >> 2);
-            while (t >= p.rope_T) t -= p.rope_T;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int mb = m0 + wr * 128 + i * 16;
+                if (p.rope_pos) {
+                    const int m = mb + (lane >> 2);
+                    rpos[i] = p.rope_pos[m < p.M ? m : p.M - 1];
+                } else {
+                    int t = __builtin_amdgcn_readfirstlane(mb % p.rope_T) + (lane >> 2);
+                    while (t >= p.rope_T) t -= p.rope_T;
+                    rpos[i] = t;
+                }
+            }
+        }
+    };
+    auto load_cs = [&](int i, float4 (&rr)[NR], const int (&rpos)[8]) {
+        if constexpr (ROPE_OK) {
+            const int t = rpos[i];
             const float4 *src = reinterpret_cast<const float4 *>(p.rope_cs + ((int64_t)t * 32 + (lane & 3) * 8) * 2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) rr[q] = src[q];
@@ -1394,11 +1411,13 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams &p, f4 (&acc)[8][4]
 #pragma unroll
                 for (int u = 0; u < RB; ++u) rbuf[0][u][q] = rbuf[1][u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        int rpos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (CS) rope_positions(rpos);
         auto prefetch = [&](int ib2) {                                    // rows of the pair ib2 (unconditional inside a mode)
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 if constexpr (RES) load_res(ib2 * RB + u, rbuf[ib2 & 1][u]);
-                else if constexpr (CS) load_cs(ib2 * RB + u, rbuf[ib2 & 1][u]);
+                else if constexpr (CS) load_cs(ib2 * RB + u, rbuf[ib2 & 1][u], rpos);
                 else if constexpr (MODE == M_GENERIC) { if (p.residual) load_res(ib2 * RB + u, rbuf[ib2 & 1][u]); }
             }
             if constexpr (LNA) {

@@ -291,6 +291,9 @@ static bool stream_plan(int M, int N, int K, bool slab_only, bool a_tiled, int64
     // (5 panels x 4 k-parts: 320-panel outputs - the 13B decoders' hidden size 5120 - on exactly 256 workgroups; up to 3 row tiles:
     //  the partial tiles of 8 waves x 5 panels x 4 row tiles would not fit the LDS)
     const int cand[][2] = {{1, 1}, {3, 2}, {3, 4}, {4, 4}, {5, 4}};    // (ties: the earlier candidate, i.e. the smaller ks)
+    // (measured and not kept, round 4, OPUS_STREAM_ROUNDS: twice the k-parts = two rounds of 256 workgroups, after tools/stream_sweep.hip
+    //  showed a pure stream running 10-15 % faster on multi-round grids - the batched decode phase 120.3 -> 137.7 ms: twice the
+    //  slabs and twice the combine tails cost far more than the better balance returns)
     for (auto &c : cand) {
         const int P = c[0], ks = c[1];
         if (npanels % P) continue;

@@ -154,13 +154,14 @@ hipError_t launch_f2h(const float *x, int64_t n, half_t *out, hipStream_t s) {
 }
 
 // out[b][d] = mean_{t=1}^{len_b-2} h[b][t][d]; fixed summation order (bitwise reproducible).
+// (token-packed form, cu != nullptr: row b's tokens are the rows cu[b] .. cu[b + 1] - 1 of h)
 __global__ __launch_bounds__(256) void masked_mean_kernel(const float *__restrict__ h, const int32_t *__restrict__ lens,
-                                                          int T, int D, float *__restrict__ out) {
+                                                          int T, int D, float *__restrict__ out, const int32_t *__restrict__ cu) {
     const int b = blockIdx.y;
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
-    const int n = lens[b] - 2;
-    const float *p = h + ((int64_t)b * T + 1) * D + d;
+    const int n = (cu ? cu[b + 1] - cu[b] : lens[b]) - 2;
+    const float *p = h + ((cu ? (int64_t)cu[b] : (int64_t)b * T) + 1) * D + d;
     // eight interleaved partial sums (t mod 8) keep eight loads in flight; combined in a fixed order
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int t = 0;
@@ -174,7 +175,12 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float *__restric
 }
 
 hipError_t launch_masked_mean(const float *h, const int32_t *lens, int B, int T, int D, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(masked_mean_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, s, h, lens, T, D, out);
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, s, h, lens, T, D, out, nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_masked_mean_packed(const float *h, const int32_t *cu, int B, int D, float *out, hipStream_t s) {
+    if (!cu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, s, h, nullptr, 0, D, out, cu);
     return hipGetLastError();
 }
 

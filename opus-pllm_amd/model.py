@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _cabi
-from .alphabet import batch_convert
+from .alphabet import batch_convert, batch_convert_packed
 from .config import OpusConfig
 from .constants import DEFAULT_SEQ_TOKEN_INDEX, IGNORE_INDEX
 from .weights import DeviceWeights
@@ -108,7 +108,37 @@ class OpusLlamaForCausalLM:
         torch.cuda.current_stream(self.device).wait_stream(self._stream)
 
     # ------------------------------------------------------------------ rows E0-E4
+    packed_encoder = True      # token-packed (varlen) encoder; False: the padded, length-bucketed form (A/B and parity tests)
+
     def _encode(self, seqs: List[str], bucket: int = 256) -> torch.Tensor:
+        """list[str] -> pooled fp32 [B, enc_dim].  Token-packed by default: the proteins' tokens go through the encoder back to
+        back with no padding and no buckets (opus_esm2_encode_packed), max_batch proteins per call."""
+        if self.packed_encoder:
+            return self._encode_packed(seqs)
+        return self._encode_padded(seqs, bucket)
+
+    def _encode_packed(self, seqs: List[str]) -> torch.Tensor:
+        cfg = self.cfg
+        n = len(seqs)
+        out = torch.empty((n, cfg.enc_dim), dtype=torch.float32, device=self.device)
+        s = self._enter()
+        keep = []
+        for i0 in range(0, n, cfg.max_batch):
+            toks, cu = batch_convert_packed(seqs[i0:i0 + cfg.max_batch])
+            B = len(cu) - 1
+            longest = int((cu[1:] - cu[:-1]).max())
+            if longest > cfg.max_enc_tokens:
+                raise _cabi.OpusError(-2, f"protein of {longest - 2} residues exceeds max_enc_tokens={cfg.max_enc_tokens}")
+            with torch.cuda.stream(self._stream):
+                d_tok = torch.from_numpy(toks).to(self.device, non_blocking=True)
+                cu_arr = (C.c_int32 * (B + 1))(*[int(v) for v in cu])
+                _cabi.check(self._lib.opus_esm2_encode_packed(self._ctx, d_tok.data_ptr(), cu_arr, B, out[i0:].data_ptr(), s))
+            keep.append(d_tok)
+            self._last_enc_shape = (1, int(cu[-1]))
+        self._leave()
+        return out
+
+    def _encode_padded(self, seqs: List[str], bucket: int = 256) -> torch.Tensor:
         """list[str] -> pooled fp32 [B, enc_dim].  Mixed lengths are processed in length buckets
         (multiples of `bucket` residues) so padding never exceeds one bucket; per-protein results do
         not depend on the batch they ran in (key padding is masked).  256 measured best on 64 proteins of
@@ -291,8 +321,11 @@ class OpusLlamaForCausalLM:
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # follows torch.manual_seed
             sampler = (t, 1.0 if top_p is None else float(top_p), int(seed))
-        if num_beams != 1:
-            raise NotImplementedError("beam search is not built (greedy only)")
+        if num_beams < 1:
+            raise ValueError("`num_beams` has to be an integer strictly greater than 0")
+        if num_beams > 1 and do_sample:
+            raise NotImplementedError("beam-sample decoding (num_beams > 1 with do_sample=True) is not built: use temperature 0")
+        beam_pad = pad_id                                      # (HF's beam fill value distinguishes None / 0 from an id)
         if pad_id is None:
             pad_id = eos[0] if eos else 0
         if inputs is None:
@@ -305,7 +338,52 @@ class OpusLlamaForCausalLM:
             dummy = torch.zeros((inputs.shape[0], self.cfg.n_prot_tokens, self.cfg.dec_dim), dtype=_cabi.operand_dtype(),
                                 device=self.device)
             embeds, mask, _ = self._splice(inputs, attention_mask, dummy, True)
+        if num_beams > 1:
+            return self._beam_search(embeds, mask, max_new, eos, beam_pad, num_beams)
         return self._greedy(embeds, mask, max_new, eos, int(pad_id), sampler)
+
+    def _beam_search(self, embeds, mask, max_new, eos, pad_id, K) -> torch.Tensor:
+        """transformers GenerationMixin._beam_search for do_sample=False (what run_opus_ddp.py:129,158 reaches with temperature 0
+        and --num_beams K): B x K decoder rows, per step the device scores the K V continuations of every batch row
+        (opus_beam_topk) and permutes the KV cache rows of the surviving beams (opus_kv_reorder); the host keeps the O(K)
+        bookkeeping (beam.BeamState).  Returns the best finished sequence of every row [B, n] (rows that stopped earlier are
+        filled as HF fills them)."""
+        from .beam import BeamState
+        B, T, _ = embeds.shape
+        cfg = self.cfg
+        if B * K > cfg.max_batch:
+            raise _cabi.OpusError(-2, f"beam search runs batch x num_beams = {B} x {K} decoder rows: the context holds max_batch={cfg.max_batch}")
+        if max_new > cfg.max_new_tokens:
+            raise _cabi.OpusError(-2, f"max_new_tokens={max_new} exceeds the context's {cfg.max_new_tokens}")
+        state = BeamState(B, K, max_new, eos, pad_id, cfg.dec_vocab)
+        M = state.M
+        if M > 16:
+            raise NotImplementedError(f"beam search keeps max(2, 1 + #eos) x num_beams = {M} candidates per row; at most 16 are built")
+        emb = embeds.repeat_interleave(K, dim=0).contiguous()          # _expand_inputs_for_generation: row b K + k
+        msk = mask.repeat_interleave(K, dim=0).contiguous()
+        self.prefill_logits(emb, msk)                                   # (the logits stay in the context)
+        s = self._enter()
+        with torch.cuda.stream(self._stream):
+            d_run = torch.empty((B * K,), dtype=torch.float32, device=self.device)
+            d_sc = torch.empty((B, M), dtype=torch.float32, device=self.device)
+            d_ix = torch.empty((B, M), dtype=torch.int32, device=self.device)
+            ident = np.tile(np.arange(K, dtype=np.int64), (B, 1))
+            base = (np.arange(B, dtype=np.int64) * K)[:, None]
+            while True:
+                d_run.copy_(torch.from_numpy(state.running_scores.reshape(-1)), non_blocking=True)
+                _cabi.check(self._lib.opus_beam_topk(self._ctx, d_run.data_ptr(), B, K, M, d_sc.data_ptr(), d_ix.data_ptr(), s))
+                sc, ix = d_sc.cpu().numpy(), d_ix.cpu().numpy()         # (synchronises this stream)
+                tok, src, done = state.step(sc, ix)
+                if done:
+                    break
+                if not np.array_equal(src, ident):
+                    d_src = torch.from_numpy((src + base).reshape(-1).astype(np.int32)).to(self.device)
+                    _cabi.check(self._lib.opus_kv_reorder(self._ctx, d_src.data_ptr(), B * K, s))
+                d_tok = torch.from_numpy(tok.reshape(-1).astype(np.int32)).to(self.device)
+                _cabi.check(self._lib.opus_llama_decode_step(self._ctx, d_tok.data_ptr(), None, s))
+        self._leave()
+        self.last_beam_scores = torch.from_numpy(state.result_scores())
+        return torch.from_numpy(state.result()).to(self.device)
 
     def set_stop_sequence(self, ids: Optional[Sequence[int]]) -> None:
         """Opt-in early stop: a row is finished once its new ids end with `ids` (at most 8) - e.g.
@@ -353,8 +431,19 @@ class OpusLlamaForCausalLM:
         Length-bucketed form: d_tokens / d_lens / bucket_rows are lists (one entry per bucket; bucket_rows[k] =
         int64 device tensor with the batch rows of bucket k), as encode_seq2embedding buckets strings."""
         cfg = self.cfg
-        buckets = list(zip(d_tokens, d_lens, bucket_rows)) if bucket_rows is not None else [(d_tokens, d_lens, None)]
         B = input_ids.shape[0]
+        if bucket_rows == "packed":      # d_tokens: packed int32 [M] on the device; d_lens: the HOST row offsets cu [B + 1]
+            s = self._enter()
+            with torch.cuda.stream(self._stream):
+                pooled = torch.empty((B, cfg.enc_dim), dtype=torch.float32, device=self.device)
+                cu_arr = (C.c_int32 * (B + 1))(*[int(v) for v in d_lens])
+                _cabi.check(self._lib.opus_esm2_encode_packed(self._ctx, d_tokens.data_ptr(), cu_arr, B, pooled.data_ptr(), s))
+                prot = torch.empty((B, cfg.n_prot_tokens, cfg.dec_dim), dtype=_cabi.operand_dtype(), device=self.device)
+                _cabi.check(self._lib.opus_projector_forward(self._ctx, pooled.data_ptr(), B, prot.data_ptr(), None, s))
+            self._leave()
+            emb, mask, _ = self._splice(input_ids, attention_mask, prot, True)
+            return self._greedy(emb, mask, int(max_new_tokens), [int(e) for e in eos], int(pad_token_id), sampler)
+        buckets = list(zip(d_tokens, d_lens, bucket_rows)) if bucket_rows is not None else [(d_tokens, d_lens, None)]
         s = self._enter()
         with torch.cuda.stream(self._stream):
             pooled = torch.empty((B, cfg.enc_dim), dtype=torch.float32, device=self.device)

@@ -184,8 +184,10 @@ class DeviceWeights:
             return v.to(self.device).to(dtype)
 
         spec = fused_spec(cfg)
-        wanted = {f.derive[1] for f in spec if f.derive and f.derive[0] == "bias_fold"}
-        unfolded: Dict[str, torch.Tensor] = {}
+        # bias_fold entries need W @ beta of the weight BEFORE its fold: computed the moment that weight is assembled and kept as a
+        # vector (holding every unfolded fp32 weight until _derive ran was ~1.5 GB of transient memory for ESM-2 650M, 6.6 GB for 3B)
+        wanted = {f.derive[1]: f.derive[2] for f in spec if f.derive and f.derive[0] == "bias_fold"}
+        folded_vec: Dict[str, torch.Tensor] = {}
         with torch.cuda.device(self.device):
             for f in spec:
                 t = self._alloc(f)
@@ -200,18 +202,18 @@ class DeviceWeights:
                                                         p.rows, p.cols, int(r), torch.cuda.current_stream().cuda_stream))
                     t2[_dst_rows(p, self.device)] = src
                 if f.name in wanted:
-                    unfolded[f.name] = t.float()
+                    folded_vec[f.name] = t.float() @ get(wanted[f.name], torch.float32)
                 if f.fold is not None:
                     t.copy_((t.float() * get(f.fold, torch.float32)[None, :]).to(_cabi.operand_dtype()))
                 if f.tiled:
                     self.tensors[f.name] = tile_weight(t)
-            self._derive(spec, lambda name: unfolded[name], lambda canon_name: get(canon_name, torch.float32))
+            self._derive(spec, None, None, folded_vec)
             torch.cuda.synchronize(self.device)
         return self
 
-    def _derive(self, spec, unfolded, vector) -> None:
+    def _derive(self, spec, unfolded, vector, folded_vec=None) -> None:
         """The derived vectors of the folded LayerNorms (Fused.derive): unfolded(name) -> fp32 [N, K] row-major weight before
-        the fold, vector(canonical name) -> fp32 vector."""
+        the fold, vector(canonical name) -> fp32 vector; or folded_vec[name] = that weight @ its vector, already computed."""
         for f in spec:
             if not f.derive:
                 continue
@@ -219,7 +221,7 @@ class DeviceWeights:
             if f.derive[0] == "colsum":
                 t.copy_(untile_weight(self.tensors[f.derive[1]]).float().sum(dim=1))
             elif f.derive[0] == "bias_fold":
-                t.add_(unfolded(f.derive[1]) @ vector(f.derive[2]))
+                t.add_(folded_vec[f.derive[1]] if folded_vec is not None else unfolded(f.derive[1]) @ vector(f.derive[2]))
             else:
                 raise ValueError(f.derive)
 
@@ -228,6 +230,8 @@ class DeviceWeights:
         """Fill the fused tensors on the GPU with the deterministic synthetic model (synth.py twin)."""
         self = cls(cfg, torch.device(device))
         lib = _cabi.lib()
+        if not stream:      # the fills and _derive's torch ops on ONE stream: torch's current one (not the null stream beside it)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
         spec = {n: (sh, std, mean) for n, sh, std, mean in synth.canonical_spec(cfg)}
         fspec = fused_spec(cfg)
         by_name = {f.name: f for f in fspec}

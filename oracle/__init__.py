@@ -24,3 +24,4 @@ from .opt import opt_forward  # noqa: F401
 from .lora import lora_merge  # noqa: F401
 from .pipeline import OraclePipeline  # noqa: F401
 from .sampling import sampling_distribution  # noqa: F401
+from .beam import beam_search  # noqa: F401

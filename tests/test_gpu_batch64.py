@@ -1,10 +1,10 @@
 """BASELINE.json configs C3 / C4 (per-GPU shard) / C5 and the full-depth C2 numerics on the GPU.
 
  * C4 shard  : Llama-3-8B shape, 64 proteins x 512 residues (what each of 8 GPUs runs for batch 512)
- * C3        : the same model, 64 proteins of mixed 128-1024 residues (seed 7), 256-residue length buckets
+ * C3        : the same model, 64 proteins of mixed 128-1024 residues (seed 7),  token-packed encoder
  * C5 shape  : Vicuna-13B + ESM2-t36-3B, 32 proteins x 1024 residues (256 / 8 GPUs)
 The CPU oracle cannot run these at full depth AND full batch in seconds, so parity is split the way the judge's brief asks:
- (1) size-independent properties at the exact shapes (a row of the batch == that row alone; bucketed == un-bucketed encode;
+ (1) size-independent properties at the exact shapes (a row of the batch == that row alone; packed == padded / bucketed encode;
      decode step == prefill of the longer prompt), each at a stated relative-L2 bound + id equality on decisive steps;
  (2) an oracle comparison at full WIDTH (every GEMM / attention kernel the batch-64 path routes through: gemm_pp, gemm_wide
      with the row-scale RMSNorm fusion, gemm_ring<2,2,8> with k-parts, gemm_mid<NORM>, grouped attn_decode) on 2 + 2 layers;
@@ -118,10 +118,12 @@ def test_c4_shard_rows_match_rows_alone(big64):
     assert int(a.min()) >= 0 and int(a.max()) < cfg.dec_vocab
 
 
-def test_c3_mixed_lengths_bucketed(big64):
-    """64 proteins of 128-1024 residues (seed 7): length buckets of 256 residues == one padded batch == rows alone, and the
-    resident-token entry bench.py times (generate_from_tokens with bucket lists) == generate() on the strings."""
-    from opus_pllm_amd.alphabet import batch_convert
+def test_c3_mixed_lengths_packed(big64):
+    """64 proteins of 128-1024 residues (seed 7) through the TOKEN-PACKED encoder (37 k token rows back to back: no padding, no
+    length buckets, one set of launches): a protein of the batch == that protein alone (packed: one row block), == the padded,
+    length-bucketed form of rounds 1-3 (256-residue buckets), and the resident-token entry bench.py times
+    (generate_from_tokens on the packed tokens) == generate() on the strings."""
+    from opus_pllm_amd.alphabet import batch_convert_packed
     cfg, model = big64
     dev = model.device
     lengths = synth.synth_lengths(64)
@@ -130,22 +132,22 @@ def test_c3_mixed_lengths_bucketed(big64):
     ids = _prompts(cfg, 64)
     order = sorted(range(64), key=lambda i: lengths[i])
     rows = (order[0], order[21], order[42], order[63])                     # shortest ... longest
+    assert model.packed_encoder
     pooled, *_ = _row_vs_batch(model, cfg, seqs, ids, rows, "c3")
-    unbucketed = model._encode(seqs, bucket=10 ** 6)                        # one batch padded to 1026 tokens
-    rel = (unbucketed - pooled).norm(dim=1) / pooled.norm(dim=1)
-    record("c3.bucketed_vs_unbucketed", float(rel.max()))
+    bucketed = model._encode_padded(seqs, bucket=256)                      # four padded batches
+    rel = (bucketed - pooled).norm(dim=1) / pooled.norm(dim=1)
+    record("c3.packed_vs_bucketed", float(rel.max()))
     assert float(rel.max()) < ROW_VS_BATCH, rel
-    # the bench entry: buckets resident in HBM
-    groups = {}
-    for i in order:
-        groups.setdefault((lengths[i] + 255) // 256, []).append(i)
-    d_tok, d_len, brow = [], [], []
-    for _, idxs in sorted(groups.items()):
-        t, l = batch_convert([seqs[i] for i in idxs])
-        d_tok.append(torch.from_numpy(t).to(dev)); d_len.append(torch.from_numpy(l).to(dev))
-        brow.append(torch.tensor(idxs, device=dev))
+    # a different packing order of the same proteins: the same embeddings (tile boundaries move: tolerance, not bits)
+    perm = list(reversed(range(64)))
+    again = model._encode_packed([seqs[i] for i in perm])
+    rel = (again[torch.tensor(perm).argsort().to(dev)] - pooled).norm(dim=1) / pooled.norm(dim=1)
+    assert float(rel.max()) < ROW_VS_BATCH, rel
+    # the bench entry: packed tokens resident in HBM
+    toks, cu = batch_convert_packed(seqs)
+    assert int(cu[-1]) == sum(lengths) + 128
     mask = torch.ones_like(ids, dtype=torch.bool)
-    a = model.generate_from_tokens(d_tok, d_len, ids.to(dev), mask.to(dev), 8, (), 0, brow)
+    a = model.generate_from_tokens(torch.from_numpy(toks).to(dev), [int(v) for v in cu], ids.to(dev), mask.to(dev), 8, (), 0, "packed")
     b = model.generate(ids, seqs, attention_mask=mask, max_new_tokens=8, pad_token_id=0)
     assert a.shape == (64, 8) and torch.equal(a, b)
 
@@ -646,3 +648,37 @@ def test_poisoned_handoff_words_fail_closed(big64):
     _cabi.check(lib.opus_debug_gemm(model._ctx, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 0, None))
     _cabi.check(lib.opus_check_error(model._ctx, None))
     assert torch.equal(out, good)
+
+
+@pytest.mark.parametrize("B,K,M", [(4, 4, 8), (16, 4, 8), (5, 3, 9), (2, 2, 4)])
+def test_beam_topk_and_cache_reorder_at_full_width(big64, B, K, M):
+    """Row N1 kernels at the Llama-3-8B vocabulary (128 256): opus_beam_topk == torch.topk(log_softmax(logits) + running scores)
+    over the flattened [K V] continuations of every batch row (indices equal, scores to fp32 rounding), and opus_kv_reorder
+    permutes the cache rows of every layer: the decode step that follows equals the step of the un-permuted rows, permuted."""
+    from opus_pllm_amd import _cabi
+    cfg, model = big64
+    dev = model.device
+    lib = _cabi.lib()
+    R, T = B * K, 24
+    g = torch.Generator().manual_seed(B * 100 + K)
+    emb = (torch.randn(R, T, cfg.dec_dim, generator=g) * 0.5).half().to(dev)
+    mask = torch.ones(R, T, dtype=torch.uint8, device=dev)
+    lg = model.prefill_logits(emb, mask)
+    run = (torch.randn(B, K, generator=g) * 2.0).to(dev)
+    run[0, 1:] = -1e9                                          # the first step's running scores
+    sc = torch.empty(B, M, device=dev)
+    ix = torch.empty(B, M, dtype=torch.int32, device=dev)
+    _cabi.check(lib.opus_beam_topk(model._ctx, run.data_ptr(), B, K, M, sc.data_ptr(), ix.data_ptr(), None))
+    torch.cuda.synchronize()
+    acc = (torch.log_softmax(lg.float(), -1).view(B, K, -1) + run[:, :, None]).view(B, -1)
+    ws, wi = torch.topk(acc, M)
+    assert torch.equal(ix.long(), wi), (ix, wi)
+    assert float((sc - ws).abs().max()) < 1e-4
+    # cache reorder: step(tokens[perm]) on the permuted cache == step(tokens) on the original cache, permuted
+    tok = torch.randint(0, cfg.dec_vocab, (R,), generator=g).to(dev)
+    perm = torch.randperm(R, generator=g).to(dev)
+    ref = model.decode_logits(tok)
+    model.prefill_logits(emb, mask)                            # (fresh cache, step counter back to 0)
+    _cabi.check(lib.opus_kv_reorder(model._ctx, perm.int().contiguous().data_ptr(), R, None))
+    got = model.decode_logits(tok[perm])
+    assert rel_l2(got, ref[perm]) < 1e-5                       # (same kernels, same rows' values: equal up to the row's position in the launch)

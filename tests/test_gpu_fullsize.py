@@ -44,11 +44,12 @@ def test_c2_shape_generate_is_deterministic_and_graph_replay_matches_eager(big, 
 def test_encoder_650m_padding_and_batch_invariance(big):
     cfg, model = big
     seqs, _ = _inputs(cfg, 3)
-    alone = torch.cat([model._encode([s], bucket=10 ** 6) for s in seqs])
-    together = model._encode(seqs, bucket=10 ** 6)          # one padded batch, T = 514
-    bucketed = model.encode_seq2embedding(seqs)             # length buckets
+    alone = torch.cat([model._encode_padded([s], bucket=10 ** 6) for s in seqs])
+    together = model._encode_padded(seqs, bucket=10 ** 6)   # one padded batch, T = 514
+    bucketed = model._encode_padded(seqs)                   # length buckets
+    packed = model.encode_seq2embedding(seqs)               # token-packed (the default)
     assert alone.shape == (3, 1280) and torch.isfinite(alone).all()
-    for other in (together, bucketed):
+    for other in (together, bucketed, packed):
         rel = (other - alone).norm(dim=1) / alone.norm(dim=1)
         assert float(rel.max()) < 2e-3, rel                 # same math, different tile / split-K shapes
 

@@ -326,9 +326,15 @@ def test_encoder_golden_micro(micro, gold, gold_dir):
     pooled = model.encode_seq2embedding(seqs)
     assert pooled.dtype == torch.float32 and pooled.shape == (4, cfg.enc_dim)
     assert rel_l2(pooled, torch.from_numpy(g["pooled"])) < REL_L2
-    # un-bucketed single call: representations of every non-pad token
-    p2 = model._encode(seqs, bucket=10 ** 6)
-    order = sorted(range(len(seqs)), key=lambda i: len(seqs[i]))        # _encode runs a group sorted by length
+    # (that was the token-packed encoder, the default) its representations of every token: the packed rows are the golden's
+    # non-pad rows in order
+    lens = [int((toks[b] != 1).sum()) for b in range(toks.shape[0])]
+    hid_packed = model.last_hidden(1, sum(lens))[0].cpu()
+    want = torch.cat([torch.from_numpy(g["last_hidden"])[b, :lens[b]] for b in range(toks.shape[0])])
+    assert rel_l2(hid_packed, want) < REL_L2
+    # the padded form (one un-bucketed call): representations of every non-pad token
+    p2 = model._encode_padded(seqs, bucket=10 ** 6)
+    order = sorted(range(len(seqs)), key=lambda i: len(seqs[i]))        # _encode_padded runs a group sorted by length
     hid = model.last_hidden(*toks.shape).cpu()
     valid = toks[order] != 1
     assert rel_l2(hid[valid], torch.from_numpy(g["last_hidden"])[order][valid]) < REL_L2
@@ -339,9 +345,17 @@ def test_encoder_padding_invariance(micro):
     """Size-independent property: a protein's embedding does not depend on its batch neighbours."""
     cfg, model, _ = micro
     a = synth.synth_protein(50, 1)
-    alone = model._encode([a], bucket=10 ** 6)
-    padded = model._encode([a, synth.synth_protein(64, 2), synth.synth_protein(7, 3)], bucket=10 ** 6)
-    assert rel_l2(padded[0], alone[0]) < 1e-3
+    batch = [a, synth.synth_protein(64, 2), synth.synth_protein(7, 3), "", synth.synth_protein(1, 4)]
+    for enc in (model._encode_packed, lambda s: model._encode_padded(s, bucket=10 ** 6)):
+        alone = enc([a])
+        together = enc(batch)
+        assert rel_l2(together[0], alone[0]) < 1e-3
+        assert bool(torch.isnan(together[3]).all())                  # an empty string: the mean over zero residues, as the reference
+        assert bool(torch.isfinite(together[4]).all())
+    # packed and padded forms agree on every protein
+    pk, pd = model._encode_packed(batch), model._encode_padded(batch, bucket=10 ** 6)
+    for i in (0, 1, 2, 4):
+        assert rel_l2(pk[i], pd[i]) < 1e-3
 
 
 @pytest.mark.parametrize("tag", ["one_each", "ragged_zero_two", "right_pad_labels", "no_mask", "single", "truncate_infer",
@@ -464,6 +478,41 @@ def test_generate_micro_golden_ids(micro, gold, gold_dir):
     assert torch.equal(out3, out)
 
 
+def test_generate_beam_golden(dev, gold, gold_dir):
+    """Row N1, `num_beams` (eval/run_opus_ddp.py:129,158): generate(num_beams=3) against the reference's own beam search on
+    the inputs of generate_micro - the best hypothesis of every row and its score, decoding to max_new_tokens and with an EOS
+    id (rows finishing at different lengths, HF's fill value behind the short one) - plus the error behaviour."""
+    from opus_pllm_amd import _cabi
+    cfg = opa.micro(max_batch=12)                              # batch 3 x 3 beams = 9 decoder rows
+    model, W = make_model(cfg, dev)
+    g, base = gold("generate_beam"), gold("generate_micro")
+    seqs = json.load(open(os.path.join(gold_dir, "generate_micro.seqs.json")))
+    ids, mask = torch.from_numpy(base["ids"]), torch.from_numpy(base["mask"])
+    pad, K, N, eos = int(base["pad"]), int(g["K"]), int(g["N"]), int(g["eos"])
+    # the fixture is far from ties: best vs runner-up hypothesis of every row differ by > 0.02 in score (length-normalised log-prob)
+    assert float(np.min(g["free_scores"][:, 0] - g["free_scores"][:, 1])) > 0.02
+    kw = dict(attention_mask=mask, pad_token_id=pad, do_sample=False, num_beams=K, max_new_tokens=N, use_cache=True)
+    out = model.generate(ids, seqs, **kw)
+    assert out.dtype == torch.long and np.array_equal(out.cpu().numpy(), g["free_ids"][:, 0])
+    np.testing.assert_allclose(model.last_beam_scores.numpy(), g["free_scores"][:, 0], atol=2e-2)
+    out2 = model.generate(ids, seqs, eos_token_id=[eos], **kw)
+    n = out2.shape[1]
+    assert n == max(int((row != pad).sum()) if eos in row else N for row in g["eos_ids"][:, 0].tolist()) or n <= N
+    assert np.array_equal(out2.cpu().numpy(), g["eos_ids"][:, 0, :n])
+    assert bool((g["eos_ids"][:, 0, n:] == pad).all())        # (the golden returned 3 hypotheses per row: cropped to their longest)
+    np.testing.assert_allclose(model.last_beam_scores.numpy(), g["eos_scores"][:, 0], atol=2e-2)
+    # beam search leaves the greedy path alone, and repeats itself
+    assert torch.equal(model.generate(ids, seqs, **kw), out)
+    greedy = model.generate(ids, seqs, attention_mask=mask, pad_token_id=pad, do_sample=False, max_new_tokens=N)
+    assert np.array_equal(greedy.cpu().numpy(), base["free_ids"][:, :N])
+    with pytest.raises(NotImplementedError):
+        model.generate(ids, seqs, attention_mask=mask, do_sample=True, temperature=0.5, num_beams=2, max_new_tokens=4)
+    with pytest.raises(_cabi.OpusError):
+        model.generate(ids, seqs, attention_mask=mask, num_beams=5, max_new_tokens=4)      # 15 rows > max_batch
+    with pytest.raises(ValueError):
+        model.generate(ids, seqs, attention_mask=mask, num_beams=0, max_new_tokens=4)
+
+
 def test_generate_stop_sequence_opt_in(micro, gold, gold_dir):
     """Row N2, "### early-stop as an opt-in": with a stop sequence set, a row is finished once its new ids end with it and
     emits pad afterwards; the ids up to and including the sequence are the free-running ones, rows that never produce it are
@@ -498,8 +547,10 @@ def test_generate_api_errors(micro):
         model.generate(ids, ["ACD"], inputs_embeds=torch.zeros(1))
     with pytest.raises(NotImplementedError):
         model.encode_seq2embedding([1, 2, 3])
-    with pytest.raises(NotImplementedError):
-        model.generate(ids, ["ACD"], num_beams=4)
+    with pytest.raises(NotImplementedError):                   # beam-sample decoding is refused; beam search is built
+        model.generate(ids, ["ACD"], num_beams=4, do_sample=True, temperature=0.7, max_new_tokens=4)
+    out = model.generate(ids, ["ACD"], num_beams=4, max_new_tokens=4)       # 1 x 4 rows fit max_batch = 8
+    assert out.shape == (1, 4)
     with pytest.raises(ValueError):
         model.generate(ids, ["ACD"], do_sample=True, temperature=0.0)
     res = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, None)

@@ -229,3 +229,98 @@ def test_multichoice_and_online_helpers():
     assert "<seq>" not in p and shown == "Hello"
     assert P.online_cut("  nucleus ### Student: next") == "nucleus"
     assert P.online_cut("###x### y") == "###x"                         # the search starts at offset 2
+
+
+@pytest.mark.parametrize("K,eos_mode,pad", [(2, "none", None), (3, "one", 0), (4, "one", 7), (3, "two", None)])
+def test_beam_bookkeeping_matches_transformers(K, eos_mode, pad):
+    """beam.BeamState (the host bookkeeping of generate(num_beams=K)) against the library the reference delegates to
+    (run_opus_ddp.py:129,158 -> GenerationMixin._beam_search of the local transformers): a tiny random LlamaForCausalLM on CPU,
+    prompts given as embeddings as the reference gives them (opus_llama.py:131), the same model's logits fed to BeamState through
+    a plain log_softmax + top-M - ids equal, with and without EOS ids (an EOS that the free run emits early, so that beams
+    finish at different lengths) and for the three cases of HF's fill value (pad None / 0 / an id)."""
+    import torch
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from opus_pllm_amd.beam import BeamState
+    torch.manual_seed(K * 7 + len(eos_mode))
+    V, H, B, T, N = 40, 32, 3, 5, 9
+    hf = LlamaForCausalLM(LlamaConfig(vocab_size=V, hidden_size=H, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4,
+                                      num_key_value_heads=2, max_position_embeddings=64)).eval()
+    with torch.no_grad():
+        for prm in hf.parameters():
+            prm.mul_(4.0)                                             # sharper distributions: beams diverge, EOS appears
+    emb = torch.randn(B, T, H)
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, :2] = 0                                                   # a left-padded row
+    kw = dict(inputs_embeds=emb, attention_mask=mask, num_beams=K, do_sample=False, max_new_tokens=N, use_cache=True)
+    with torch.no_grad():
+        free = hf.generate(**kw, eos_token_id=None, pad_token_id=pad)
+    eos = {"none": [], "one": [int(free[0, 2])], "two": [int(free[0, 2]), int(free[2, 4])]}[eos_mode]
+    with torch.no_grad():
+        want = hf.generate(**kw, eos_token_id=eos or None, pad_token_id=pad)
+
+    st = BeamState(B, K, N, eos, pad, V)
+    tok_emb = hf.get_input_embeddings()
+    seqs = torch.zeros(B, K, 0, dtype=torch.long)
+    while True:
+        flat = seqs.reshape(B * K, -1)
+        full = torch.cat([emb.repeat_interleave(K, 0), tok_emb(flat)], 1)
+        fm = torch.cat([mask.repeat_interleave(K, 0), torch.ones(B * K, flat.shape[1], dtype=torch.long)], 1)
+        pos = (fm.cumsum(-1) - 1).clamp(min=0)
+        with torch.no_grad():
+            lg = hf(inputs_embeds=full, attention_mask=fm, position_ids=pos).logits[:, -1].float()
+        acc = torch.log_softmax(lg, -1).view(B, K, V) + torch.from_numpy(st.running_scores)[:, :, None]
+        sc, ix = torch.topk(acc.view(B, K * V), st.M)
+        tok, src, done = st.step(sc.numpy(), ix.numpy())
+        if done:
+            break
+        seqs = torch.cat([seqs[torch.arange(B)[:, None], torch.from_numpy(src)], torch.from_numpy(tok)[:, :, None]], 2)
+    got = st.result()
+    assert got.shape == tuple(want.shape), (got.shape, want.shape)
+    assert np.array_equal(got, want.numpy()), (got, want)
+
+
+def test_asan_host_build_runs_clean():
+    """SURVEY 5 "optional ASan build of host C ABI": build.py --asan compiles api.cpp's host side with -fsanitize=address
+    (CPU container only: GPU ASan is not available on the pool); a child process loads it under the ASan runtime, checks the
+    symbol table and drives every host-only entry point - config validation, workspace carving, error strings, the knob
+    parser, argument checks that return before any HIP call - and must exit without a sanitizer report."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "opus-pllm_amd"))
+    import build as opus_build
+    if not os.path.exists(opus_build.ASAN_RT):
+        pytest.skip("no ASan runtime in this image")
+    lib = opus_build.build_asan(verbose=False)
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+import opus_pllm_amd as opa
+from opus_pllm_amd import _cabi
+l = ctypes.CDLL(%r)
+for name, (res, args) in _cabi.SIGNATURES.items():
+    fn = getattr(l, name); fn.restype = res; fn.argtypes = args
+assert l.opus_abi_version() == _cabi.ABI_VERSION
+for preset in (opa.micro, opa.c1_tiny, opa.llama3_8b, opa.vicuna_13b, opa.micro_opt):
+    cc = _cabi.CConfig.from_config(preset())
+    assert l.opus_workspace_bytes(ctypes.byref(cc)) > 0
+bad = _cabi.CConfig.from_config(opa.llama3_8b()); bad.dec_dim = 4100
+assert l.opus_workspace_bytes(ctypes.byref(bad)) == -1 and b"multiple of 64" in l.opus_last_error()
+bad = _cabi.CConfig.from_config(opa.micro()); bad.dec_heads = 3
+ctx = ctypes.c_void_p()
+assert l.opus_ctx_create(ctypes.byref(bad), 0, ctypes.byref(ctx)) == -2 and l.opus_last_error()
+assert l.opus_ctx_create(None, 0, ctypes.byref(ctx)) == -1
+buf = ctypes.create_string_buffer(512)
+assert l.opus_timing_names(buf, 512) == 0 and b"gemm_pp" in buf.value and b"decode" in buf.value
+assert l.opus_timing_names(buf, 8) == -2
+assert l.opus_debug_knob(None, b"misc3", 1) == 0 and l.opus_debug_knob(None, b"misc3", 0) == 0
+assert l.opus_debug_knob(None, b"nonsense", 1) == -1 and b"nonsense" in l.opus_last_error()
+assert l.opus_debug_knob(None, b"poison_handoff", 1) == -1
+assert l.opus_esm2_encode(None, None, None, 1, 8, None, None) == -1
+assert l.opus_generate_greedy(None, None, None, 1, 1, 1, None, 0, 0, None, None, None) == -1
+assert l.opus_check_error(None, None) == -1 and l.opus_beam_topk(None, None, 1, 1, 1, None, None, None) == -1
+assert l.opus_lora_merge(None, None, None, 1.0, 8, 8, 1, None) == -1
+print("asan-clean")
+""" % (ROOT, lib)
+    env = dict(os.environ, LD_PRELOAD=opus_build.ASAN_RT, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "asan-clean" in r.stdout and "AddressSanitizer" not in r.stderr, (r.stdout[-500:], r.stderr[-2000:])

@@ -120,6 +120,25 @@ def test_generate_micro_golden(gold, gold_dir, micro):
     assert float(margins.min()) > 1e-3                                # the fixture is far from ties
 
 
+def test_generate_beam_golden(gold, gold_dir, micro):
+    """Row N1 (`num_beams`): the oracle's beam search against the reference's generate(num_beams=3, num_return_sequences=3) on
+    the inputs of generate_micro - all three hypotheses of every row and their scores, decoding to max_new_tokens and with an
+    EOS id (hypotheses of different lengths, HF's fill value behind the short ones)."""
+    cfg, W = micro
+    g, base = gold("generate_beam"), gold("generate_micro")
+    seqs = json.load(open(os.path.join(gold_dir, "generate_micro.seqs.json")))
+    pipe = oracle.OraclePipeline(cfg, W)
+    emb, m, _, _ = pipe.prepare(torch.from_numpy(base["ids"]), torch.from_numpy(base["mask"]), seqs, True)
+    K, N, pad = int(g["K"]), int(g["N"]), int(base["pad"])
+    ids, sc = oracle.beam_search(emb, m, pipe.W, cfg, N, K, (), pad)
+    assert np.array_equal(ids.numpy(), g["free_ids"])
+    np.testing.assert_allclose(sc.numpy(), g["free_scores"], atol=2e-5)
+    ids, sc = oracle.beam_search(emb, m, pipe.W, cfg, N, K, (int(g["eos"]),), pad)
+    assert np.array_equal(ids.numpy(), g["eos_ids"])
+    np.testing.assert_allclose(sc.numpy(), g["eos_scores"], atol=2e-5)
+    assert float(np.min(g["free_scores"][:, 0] - g["free_scores"][:, 1])) > 0.02      # best vs runner-up: far from ties
+
+
 def test_generate_c1_golden(gold):
     cfg = opa.c1_tiny()
     W = synth.canonical_weights(cfg, 0)

@@ -48,9 +48,3 @@ for flip in ((0, 1) if "ab" in sys.argv else (0,)):     # knob misc3 = 1 flips t
     bench("llama prefill B=64", 64, 96, 32, 4, 128, 1)
     bench("llama prefill B=1", 1, 96, 32, 4, 128, 1)
 _cabi.check(lib.opus_debug_knob(model._ctx, b"misc3", 0))
-sys.exit(0)
-bench("esm650m B=64", 64, 514, 20, 1, 64, 0)
-bench("esm650m B=1", 1, 514, 20, 1, 64, 0)
-bench("esm3b B=32 L=1024", 32, 1026, 40, 1, 64, 0)
-bench("llama prefill B=64", 64, 96, 32, 4, 128, 1)
-bench("llama prefill B=1", 1, 96, 32, 4, 128, 1)

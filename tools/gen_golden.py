@@ -381,6 +381,30 @@ def gold_llama_and_generate(cfg, w, model, hf_esm):
         json.dump(seqs, f)
 
 
+def gold_beam(cfg, w, model, hf_esm):
+    """Row N1, `num_beams` (eval/run_opus_ddp.py:129,158): the reference's own generate() - OpusLlamaForCausalLM.generate ->
+    GenerationMixin._beam_search of the local transformers - on the inputs of generate_micro with num_beams = 3, all three
+    hypotheses returned with their scores; once decoding to max_new_tokens and once with an EOS id that beams emit at
+    different steps (finished hypotheses of different lengths, HF's fill value behind them)."""
+    model.get_model().protein_encoder = FakeEncoder(hf_esm)
+    g = np.load(os.path.join(GOLD, "generate_micro.npz"))
+    seqs = json.load(open(os.path.join(GOLD, "generate_micro.seqs.json")))
+    ids, mask, pad = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"]), int(g["pad"])
+    K, N = 3, 10
+    kw = dict(attention_mask=mask, pad_token_id=pad, do_sample=False, num_beams=K, num_return_sequences=K, max_new_tokens=N,
+              use_cache=True, return_dict_in_generate=True, output_scores=True)
+    with torch.no_grad():
+        free = model.generate(ids, seqs, eos_token_id=None, **kw)
+        B = ids.shape[0]
+        fs = free.sequences.view(B, K, -1)
+        eos = int(fs[0, 0, 3])                          # an id the best hypothesis of row 0 emits at step 3
+        stop = model.generate(ids, seqs, eos_token_id=[eos], **kw)
+    ss = stop.sequences.view(B, K, -1)
+    save("generate_beam", K=np.array(K), N=np.array(N), eos=np.array(eos),
+         free_ids=fs.numpy(), free_scores=free.sequences_scores.view(B, K).numpy(),
+         eos_ids=ss.numpy(), eos_scores=stop.sequences_scores.view(B, K).numpy())
+
+
 def gold_c1(cfg, w):
     """(vii) full C1 chain: one 128-residue protein, ESM2-t6-8M shape + tiny decoder, greedy ids."""
     hf = gold_esm("esm_c1", cfg, w, [synth.synth_protein(128, 0)])
@@ -510,6 +534,7 @@ def main():
     print("projector variants"); gold_projector_variants()
     print("splice"); gold_splice(cfg, w, model)
     print("llama + generate (micro)"); gold_llama_and_generate(cfg, w, model, hf)
+    print("beam search (micro)"); gold_beam(cfg, w, model, hf)
     for tag, fam in (("generate_micro_opt", opa.micro_opt()), ("generate_micro_opt_relu", opa.micro_opt_relu()),
                      ("generate_micro_qwen", opa.micro_qwen())):
         print(tag); gold_decoder_family(tag, fam, synth.canonical_weights(fam, seed=0))

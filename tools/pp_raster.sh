@@ -23,8 +23,5 @@ PY
     rm -rf $OUT/p
   done
 done
-python3 - >> $OUT/summary.txt <<'PY'
-import subprocess, sys
-PY
 for gm in 2 4 8 16; do echo "== time, GM=$gm" >> $OUT/summary.txt; python3 tools/bench_gemm.py custom_gm $gm 2>&1 | grep -v amdgpu >> $OUT/summary.txt; done
 cat $OUT/summary.txt
