@@ -294,6 +294,10 @@ static bool stream_plan(int M, int N, int K, bool slab_only, bool a_tiled, int64
     // (measured and not kept, round 4, OPUS_STREAM_ROUNDS: twice the k-parts = two rounds of 256 workgroups, after tools/stream_sweep.hip
     //  showed a pure stream running 10-15 % faster on multi-round grids - the batched decode phase 120.3 -> 137.7 ms: twice the
     //  slabs and twice the combine tails cost far more than the better balance returns)
+    // (measured and not kept, round 4: the gate / up projection through this kernel - 4 panels (two gate / up pairs) x the whole K per
+    //  workgroup, 448 workgroups in 1.75 rounds, silu(g) u + the row scale in the combine - parity-green and 58 us per launch against
+    //  gemm_wide_kernel's 45.8: every workgroup re-reads the whole activation matrix from L2, 229 MB beside 235 MB of weights, and a
+    //  CU's L1 takes in ~67 GB/s)
     for (auto &c : cand) {
         const int P = c[0], ks = c[1];
         if (npanels % P) continue;

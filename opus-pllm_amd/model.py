@@ -306,7 +306,8 @@ class OpusLlamaForCausalLM:
         temperature = kwargs.pop("temperature", None)
         top_p = kwargs.pop("top_p", None)
         seed = kwargs.pop("seed", None)
-        num_beams = int(kwargs.pop("num_beams", 1) or 1)
+        num_beams = kwargs.pop("num_beams", 1)
+        num_beams = 1 if num_beams is None else int(num_beams)
         max_new = int(kwargs.pop("max_new_tokens", 32))
         kwargs.pop("use_cache", None)
         self.set_stop_sequence(kwargs.pop("stop_sequence", None))          # extension (opt-in "###" early stop), see below

@@ -27,10 +27,10 @@ MARGIN_TAU = 0.05
 # Fraction of a fixture's greedy ids that lie before each row's first low-margin step (oracle top-1 margin < MARGIN_TAU)
 # and therefore MUST match bit for bit.  It is a property of the fixture and the oracle alone (the margins come from the
 # oracle), so the bounds are the exact values: C1 and the mid-size model have no low-margin step at all (smallest margins
-# 0.0745 and 0.0957), the OPT / Qwen2 micro fixtures have 28 of 36 ids before their rows' first near-tie.
+# 0.0745 and 0.0957); the OPT / Qwen2 micro fixtures (round 4: weights seeds chosen by margin) are decisive on all 36 ids.
 C1_IDS_FRACTION = 1.0
 MIDSIZE_IDS_FRACTION = 1.0
-FAMILY_IDS_FRACTION = {"generate_micro_opt": 28 / 36, "generate_micro_opt_relu": 18 / 36, "generate_micro_qwen": 28 / 36}
+FAMILY_IDS_FRACTION = {"generate_micro_opt": 1.0, "generate_micro_opt_relu": 1.0, "generate_micro_qwen": 1.0}
 
 
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -497,7 +497,7 @@ def test_generate_beam_golden(dev, gold, gold_dir):
     np.testing.assert_allclose(model.last_beam_scores.numpy(), g["free_scores"][:, 0], atol=2e-2)
     out2 = model.generate(ids, seqs, eos_token_id=[eos], **kw)
     n = out2.shape[1]
-    assert n == max(int((row != pad).sum()) if eos in row else N for row in g["eos_ids"][:, 0].tolist()) or n <= N
+    assert n <= N
     assert np.array_equal(out2.cpu().numpy(), g["eos_ids"][:, 0, :n])
     assert bool((g["eos_ids"][:, 0, n:] == pad).all())        # (the golden returned 3 hypotheses per row: cropped to their longest)
     np.testing.assert_allclose(model.last_beam_scores.numpy(), g["eos_scores"][:, 0], atol=2e-2)
@@ -697,8 +697,8 @@ def test_decoder_family_golden(dev, gold, tag, preset, on_gpu_fill):
     the transformers goldens: prefill + 4 teacher-forced step logits, greedy ids, hipGraph replay; weights both from
     the canonical host tensors and from the on-device synthetic fill."""
     cfg = opa.PRESETS[preset]()
-    model, W = make_model(cfg, dev, synthetic_on_gpu=on_gpu_fill)
     base, g = gold("generate_micro"), gold(tag)
+    model, W = make_model(cfg, dev, seed=int(g["weights_seed"]), synthetic_on_gpu=on_gpu_fill)
     emb = torch.from_numpy(base["embeds"]).half()
     mask = torch.from_numpy(base["mask_out"]).bool()
     ref = torch.from_numpy(g["step_logits"])
@@ -712,7 +712,7 @@ def test_decoder_family_golden(dev, gold, tag, preset, on_gpu_fill):
     import oracle
     _, margins, _ = oracle.greedy_decode(emb.float(), mask, W, cfg, free.shape[1], (), 2)
     out = model._greedy(emb.to(dev), mask.to(dev), free.shape[1], [], 2)
-    # bit-exact ids up to each row's first low-margin step (these fixtures do contain near-ties)
+    # bit-exact ids on the whole fixture: its weights seed was chosen so that no id is decided by a near-tie (gen_golden.py)
     frac = _check_ids(out, free, margins)
     from gpu_helpers import record
     record(tag + ".ids_checked_fraction", frac)

@@ -176,11 +176,12 @@ def test_decoder_family_golden(gold, tag, preset):
     """Row N4: the OPT / Galactica and Qwen2 restatements against the local transformers models (prefill + 4
     teacher-forced steps, and the greedy ids of generate(inputs_embeds=...)) on the spliced inputs of generate_micro."""
     cfg = opa.PRESETS[preset]()
-    W = {k: torch.from_numpy(v) for k, v in synth.canonical_weights(cfg, 0).items()}
     base, g = gold("generate_micro"), gold(tag)
+    W = {k: torch.from_numpy(v) for k, v in synth.canonical_weights(cfg, int(g["weights_seed"])).items()}
     emb, mask = torch.from_numpy(base["embeds"]).float(), torch.from_numpy(base["mask_out"]).bool()
     free = torch.from_numpy(g["free_ids"])
     ids, margins, logits = oracle.greedy_decode(emb, mask, W, cfg, free.shape[1], (), 2)
     assert torch.equal(ids, free), (ids, free)
+    assert float(margins.min()) > 0.09 and abs(float(margins.min()) - float(g["min_margin"])) < 1e-3    # no near-tie in the fixture
     _, _, tf = oracle.greedy_decode(emb, mask, W, cfg, 5, (), 2, forced=free[:, :5])
     np.testing.assert_allclose(tf.transpose(0, 1).numpy(), g["step_logits"], atol=3e-5, rtol=1e-4)

@@ -418,7 +418,23 @@ def gold_c1(cfg, w):
 
 
 
-def gold_decoder_family(tag, cfg, w):
+def gold_decoder_family(tag, cfg, w=None):
+    """The fixture of one decoder family, from the first synthetic-weights seed (0, 1, 2, ...) whose greedy run keeps every one of
+    its 36 ids away from a near-tie (top-1 margin of the deciding logits >= 0.10): the GPU test can then demand bit-exact ids on
+    the whole fixture instead of up to each row's first low-margin step (round 3: 18 - 28 of 36).  The seed is stored."""
+    best = None
+    for seed in range(64):
+        arrs, mm = _decoder_family_run(cfg, synth.canonical_weights(cfg, seed=seed))
+        if best is None or mm > best[2]:
+            best = (seed, arrs, mm)
+        if mm >= 0.10:
+            break
+    seed, arrs, mm = best
+    print(f"  {tag}: weights seed {seed}, smallest top-1 margin over the greedy run {mm:.3f}")
+    save(tag, weights_seed=np.array(seed), min_margin=np.array(mm, dtype=np.float32), **arrs)
+
+
+def _decoder_family_run(cfg, w):
     """Row N4: decoder families other than Llama.  The reference's wrappers (opus_opt.py, opus_qwen.py) only route
     `inputs_embeds` into the stock transformers model, so the golden is the LOCAL transformers OPTForCausalLM /
     Qwen2ForCausalLM run on the spliced embeddings of generate_micro (same prompt rows, same protein features):
@@ -478,8 +494,15 @@ def gold_decoder_family(tag, cfg, w):
         fmask = torch.cat([amask, torch.ones(emb.shape[0], 4, dtype=amask.dtype)], dim=1)
         kw = {} if cfg.dec_arch == 1 else dict(position_ids=(fmask.cumsum(-1) - 1).clamp(min=0))
         logits = model(inputs_embeds=full, attention_mask=fmask, **kw).logits
+        # top-1 margins of the whole greedy run (teacher-forced on its own ids: the logits that decided each id)
+        allin = torch.cat([emb, model.get_input_embeddings()(free[:, :-1])], dim=1)
+        allm = torch.cat([amask, torch.ones(emb.shape[0], N - 1, dtype=amask.dtype)], dim=1)
+        kw2 = {} if cfg.dec_arch == 1 else dict(position_ids=(allm.cumsum(-1) - 1).clamp(min=0))
+        dec = model(inputs_embeds=allin, attention_mask=allm, **kw2).logits[:, emb.shape[1] - 1:]
+        top2 = dec.topk(2, dim=-1).values
+        assert torch.equal(dec.argmax(-1), free)
     T = emb.shape[1]
-    save(tag, free_ids=free.numpy(), step_logits=logits[:, T - 1:T + 4].numpy())
+    return dict(free_ids=free.numpy(), step_logits=logits[:, T - 1:T + 4].numpy()), float((top2[..., 0] - top2[..., 1]).min())
 
 
 def gold_conversation():
@@ -537,7 +560,7 @@ def main():
     print("beam search (micro)"); gold_beam(cfg, w, model, hf)
     for tag, fam in (("generate_micro_opt", opa.micro_opt()), ("generate_micro_opt_relu", opa.micro_opt_relu()),
                      ("generate_micro_qwen", opa.micro_qwen())):
-        print(tag); gold_decoder_family(tag, fam, synth.canonical_weights(fam, seed=0))
+        print(tag); gold_decoder_family(tag, fam)
     print("C1 chain")
     c1 = opa.c1_tiny()
     gold_c1(c1, synth.canonical_weights(c1, seed=0))
