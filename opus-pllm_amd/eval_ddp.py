@@ -132,7 +132,7 @@ def eval_model(args):
     # capacity of the context: the reference has no cap; here the KV cache is sized once, from what this run will really ask for
     tokenizer, model, _ = load_pretrained_model(args.model_base_path, args.opus_pllm_weights_path, model_name,
                                                 args.load_8bit, args.load_4bit, switch_projector_type=args.switch_projector_type,
-                                                cstp_path=cstp_path, device=f"cuda:{local}", max_batch=args.batch_size,
+                                                cstp_path=cstp_path, device=f"cuda:{local}", max_batch=args.batch_size * max(1, args.num_beams),
                                                 max_enc_tokens=args.max_residues + 2, max_prompt=8, max_new_tokens=max_new,
                                                 capacity_from=lambda tok, cfg: dict(
                                                     max_prompt=max(args.max_prompt or 0, prompt_capacity(tok, mine, args.input_path, cfg.n_prot_tokens))))

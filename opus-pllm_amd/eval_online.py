@@ -44,7 +44,7 @@ def eval_model(args):
     cstp_path = return_cstp_path(args.opus_pllm_weights_path, "modality_encoder/modality_encoding_adapter.ckpt")
     tokenizer, model, _ = load_pretrained_model(args.model_base_path, args.opus_pllm_weights_path, model_name,
                                                 args.load_8bit, args.load_4bit, switch_projector_type=args.switch_projector_type,
-                                                cstp_path=cstp_path, device="cuda:0", max_batch=1,
+                                                cstp_path=cstp_path, device="cuda:0", max_batch=max(1, args.num_beams),
                                                 max_enc_tokens=args.max_residues + 2, max_prompt=args.max_prompt,
                                                 max_new_tokens=max(args.max_new_tokens, 1))
     while True:

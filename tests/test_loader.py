@@ -282,6 +282,12 @@ def test_two_stage_eval_loop_projects_the_shard_once(tmp_path):
     assert torch.equal(draws[0], draws[1]) and torch.equal(draws[1], draws[2])
     torch.manual_seed(78)
     assert not torch.equal(ddp.annotate(model, tok, items, "", 4, 8, temperature=0.9, top_p=0.95, inflight=2), draws[0])
+    # --num_beams through the driver (run_opus_ddp.py:129,158): batches of 2 x 2 beams fit this context's 4 rows; an item's
+    # beams do not depend on its batch neighbours (batch of 2 == batch of 1), and two contexts in flight return the same ids
+    bm2 = ddp.annotate(model, tok, items[:6], "", 2, 8, num_beams=2)
+    bm1 = ddp.annotate(model, tok, items[:6], "", 1, 8, num_beams=2)
+    assert bm2.shape == (6, 8) and torch.equal(bm2, bm1)
+    assert torch.equal(ddp.annotate(model, tok, items[:6], "", 2, 8, num_beams=2, inflight=2), bm2)
 
 
 @pytest.mark.gpu
