@@ -2196,6 +2196,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
     }
 }
 
+// (measured and not kept, round 4: a 16-wave form of gemm_wide_kernel - two waves per panel, each taking half of every 8-chunk
+//  stage, weights two stages ahead in an 8-chunk register ring: 256 KB of loads in flight per CU instead of 64, the depth at which
+//  tools/stream_sweep.hip streams 235 MB at 7.5 TB/s.  Parity-green, 114 VGPRs, no scratch - and SLOWER: gate / up 49.7 vs 42.9 us,
+//  lm_head 226 vs 189 us in isolation (tools/bench_gemm.py wide16 of that commit), the decode phase +6.5 ms.  The queue depth of a
+//  pure stream is not what limits this kernel.)
 template <int MT, int EPI>
 static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
     const int blocks = cdiv((p.N + 15) >> 4, 8), chunks = p.K / 64;
