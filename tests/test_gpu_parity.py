@@ -358,6 +358,33 @@ def test_encoder_padding_invariance(micro):
         assert rel_l2(pk[i], pd[i]) < 1e-3
 
 
+def test_encoder_packed_api_edges(micro, dev):
+    """opus_esm2_encode_packed beyond the happy path: more proteins than the context's max_batch (chunked by the host mirror), the
+    longest protein the context holds, and the argument errors of the C entry point (no kernel is launched for any of them)."""
+    import ctypes as C
+    from opus_pllm_amd import _cabi
+    cfg, model, _ = micro
+    seqs = [synth.synth_protein(3 + 5 * i, i) for i in range(11)] + [synth.synth_protein(cfg.max_enc_tokens - 2, 99)]
+    assert len(seqs) > cfg.max_batch
+    together = model._encode_packed(seqs)
+    alone = torch.cat([model._encode_packed([s]) for s in seqs])
+    assert together.shape == (12, cfg.enc_dim) and rel_l2(together, alone) < 1e-3
+    with pytest.raises(_cabi.OpusError):
+        model._encode_packed([synth.synth_protein(cfg.max_enc_tokens - 1, 0)])           # one residue too many
+    lib = _cabi.lib()
+    tok = torch.zeros(64, dtype=torch.int32, device=dev)
+    out = torch.empty(4, cfg.enc_dim, device=dev)
+
+    def call(cu, B):
+        arr = (C.c_int32 * len(cu))(*cu)
+        return lib.opus_esm2_encode_packed(model._ctx, tok.data_ptr(), arr, B, out.data_ptr(), None)
+    assert call([1, 5], 1) == -1                                   # cu[0] != 0
+    assert call([0, 1], 1) == -2                                   # a row shorter than <cls><eos>
+    assert call([0, cfg.max_enc_tokens + 1], 1) == -2              # a row longer than the context's max_enc_tokens
+    assert call([0, 4], 0) == -2 and call([0] + [3] * cfg.max_batch + [6], cfg.max_batch + 1) == -2
+    assert lib.opus_esm2_encode_packed(model._ctx, None, None, 1, None, None) == -1
+
+
 @pytest.mark.parametrize("tag", ["one_each", "ragged_zero_two", "right_pad_labels", "no_mask", "single", "truncate_infer",
                                  "truncate_train"])
 def test_splice_golden_bit_exact(micro, gold, tag):

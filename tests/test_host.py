@@ -231,7 +231,8 @@ def test_multichoice_and_online_helpers():
     assert P.online_cut("###x### y") == "###x"                         # the search starts at offset 2
 
 
-@pytest.mark.parametrize("K,eos_mode,pad", [(2, "none", None), (3, "one", 0), (4, "one", 7), (3, "two", None)])
+@pytest.mark.parametrize("K,eos_mode,pad", [(2, "none", None), (3, "one", 0), (4, "one", 7), (3, "two", None), (3, "first", 5),
+                                            (2, "first3", None)])
 def test_beam_bookkeeping_matches_transformers(K, eos_mode, pad):
     """beam.BeamState (the host bookkeeping of generate(num_beams=K)) against the library the reference delegates to
     (run_opus_ddp.py:129,158 -> GenerationMixin._beam_search of the local transformers): a tiny random LlamaForCausalLM on CPU,
@@ -254,7 +255,10 @@ def test_beam_bookkeeping_matches_transformers(K, eos_mode, pad):
     kw = dict(inputs_embeds=emb, attention_mask=mask, num_beams=K, do_sample=False, max_new_tokens=N, use_cache=True)
     with torch.no_grad():
         free = hf.generate(**kw, eos_token_id=None, pad_token_id=pad)
-    eos = {"none": [], "one": [int(free[0, 2])], "two": [int(free[0, 2]), int(free[2, 4])]}[eos_mode]
+    # "first": an id that a best hypothesis starts with (a row finishes at length 1; the early-stop heuristic ends the search);
+    # "first3": the first ids of all three rows (every row finishes early: the loop ends long before max_new_tokens)
+    eos = {"none": [], "one": [int(free[0, 2])], "two": [int(free[0, 2]), int(free[2, 4])], "first": [int(free[1, 0])],
+           "first3": [int(free[0, 0]), int(free[1, 0]), int(free[2, 0])]}[eos_mode]
     with torch.no_grad():
         want = hf.generate(**kw, eos_token_id=eos or None, pad_token_id=pad)
 
