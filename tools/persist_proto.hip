@@ -6,7 +6,8 @@
 //   B  ONE launch per step, a grid barrier between phases                        (decode_stack.hip of round 1, removed in round 3)
 //   C  B + the first 8 loads per wave of the NEXT phase requested BEFORE the barrier (weights do not depend on the barrier:
 //      128 KB per CU = 32 MB chip-wide in flight while the barrier runs)        (cdna_hip_programming.md 5.6, prefetch-credit)
-//   each of B / C with and without the agent-scope release / acquire fences a real hand-off of activations needs.
+//   each of B / C with and without the agent-scope release / acquire fences a real hand-off of activations needs;
+//   D  B / C with the XCD-hierarchical barrier of MI355X_MICROARCH.md (8 group counters + a top counter) instead of one counter.
 // Prints microseconds per layer.  Build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/persist_proto tools/persist_proto.hip && gpurun_out/persist_proto
 #include <hip/hip_runtime.h>
@@ -102,6 +103,67 @@ __device__ __forceinline__ bool grid_barrier(unsigned *cnt, unsigned target, uns
     return true;
 }
 
+// XCD-hierarchical form (MI355X_MICROARCH.md "barrier-xcd"): workgroups that share blockIdx.x % 8 (one XCD under round-robin
+// placement: a speed matter only) count on their own line; the last arriver of a group counts on the top word, waits for the
+// other groups there and releases its group through the group's generation word - 32 pollers per line instead of 256 on one.
+// hb: [8 groups][32 words: cnt at 0, gen at 16] then the top counter at word 256.
+__device__ __forceinline__ void grid_barrier_xcd(unsigned *hb, unsigned epoch, unsigned *err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int g = blockIdx.x & 7;
+        unsigned *gc = hb + g * 32, *gg = hb + g * 32 + 16, *top = hb + 256;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned old = __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        if (old + 1 == (NWG / 8) * epoch) {                                  // last of its group
+            __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8 * epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { *err = 1; break; }
+            }
+            __hip_atomic_store(gg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { *err = 1; break; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <bool PREFETCH>
+__global__ __launch_bounds__(NT) void step_kernel_xcd(Step st, unsigned *hb, unsigned base, unsigned *out, unsigned *err) {
+    extern __shared__ char sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u4 acc = {0, 0, 0, 0};
+    u4 pre[U];
+    bool have = false;
+    unsigned nb = 0;
+    for (int l = 0; l < st.nlayers; ++l) {
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            long long lo, hi;
+            share(st.l[l].n16[ph], blockIdx.x, wave, lo, hi);
+            acc ^= stream_body(st.l[l].w[ph], lo, hi, lane, pre, have);
+            have = false;
+            if (PREFETCH) {
+                const int l2 = ph + 1 < NPH ? l : l + 1, p2 = ph + 1 < NPH ? ph + 1 : 0;
+                if (l2 < st.nlayers) {
+                    long long lo2, hi2;
+                    share(st.l[l2].n16[p2], blockIdx.x, wave, lo2, hi2);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) pre[u] = ntload(st.l[l2].w[p2] + (lo2 + u) * 64 + lane);
+                    have = true;
+                }
+            }
+            ++nb;
+            grid_barrier_xcd(hb, base + nb, err);
+        }
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[blockIdx.x] = 1;
+}
+
 template <bool PREFETCH, bool FENCE>
 __global__ __launch_bounds__(NT) void step_kernel(Step st, unsigned *cnt, unsigned base, unsigned *out, unsigned *err) {
     extern __shared__ char sm[];
@@ -190,6 +252,22 @@ int main() {
     persist(step_kernel<false, true>,  "B' one launch, grid barriers, release/acquire fences: ");
     persist(step_kernel<true, false>,  "C  B + next phase's loads before the barrier:         ");
     persist(step_kernel<true, true>,   "C' B' + next phase's loads before the barrier:        ");
+    {   // D: the XCD-hierarchical barrier
+        unsigned *hb; hipMalloc(&hb, 4096); hipMemset(hb, 0, 4096);
+        hipFuncSetAttribute((const void *)step_kernel_xcd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void *)step_kernel_xcd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        unsigned ebase = 0;
+        auto persist_x = [&](auto kern, const char *name) {
+            const double t = time_it([&] {
+                hipLaunchKernelGGL(kern, dim3(NWG), dim3(NT), lds, s, st, hb, ebase, out, err);
+                ebase += (unsigned)(L * NPH);
+            });
+            unsigned e = 0; hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost);
+            printf("%s %7.2f us per layer  (%+.2f vs A)%s\n", name, t, t - a, e ? "  [BARRIER TIMEOUT]" : "");
+        };
+        persist_x(step_kernel_xcd<false>, "D  one launch, XCD-hierarchical barriers, no fences:    ");
+        persist_x(step_kernel_xcd<true>,  "D' D + next phase's loads before the barrier:          ");
+    }
     const double a2 = time_it([&] { hipGraphLaunch(ge, s); });
     printf("A  again:                                                %7.2f us per layer\n", a2);
     // sweep: the gate / up stream alone (235 MB, one launch per layer's buffer, 32 launches in a graph)
