@@ -355,6 +355,10 @@ static hipError_t launch_hd(const AttnParams &p, hipStream_t s) {
     // 240 VGPRs (batch-64 decoder prefill, 96 positions, causal: 47.8 vs 50.6 us; batch 1: 7.0 vs 8.6 us).
     // (Not kept: the ragged last query block - T = 514 leaves 2 of 128 queries - as a second launch of the one-tile form:
     //  167 vs 158-165 us on one box; the 19-30 % that block costs varies more between boxes than the split recovers.)
+    // (Not kept, round 4: a fifth wave per workgroup that is alive only in a row's last block and takes the <= 32 queries
+    //  behind it, so that T = 514 needs 4 blocks instead of 5.  320-thread workgroups at 157 VGPRs fit two to a CU (10 of 12
+    //  wave slots) where 256-thread ones fit three, and the fifth waves that leave at once do not give the slots back in
+    //  time: 64 x 514: 281 vs 167 us, 64 x 512: 158 vs 138 us, 32 x 1026 x 40: 685 vs 542 us.)
     bool one = !(HD <= 64 && (int64_t)p.B * p.heads * cdiv(p.T, 128) >= 512);
     if (g_knobs.misc[3]) one = !one;                                 // A/B aid
     return one ? launch_qt<HD, 1>(p, s) : launch_qt<HD, 2>(p, s);

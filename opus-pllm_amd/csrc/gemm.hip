@@ -1764,6 +1764,14 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
         const double t_tile = 1.5 * KT + 12.0, gain = t_tile * (1.0 - 1.0 / sp), cost = (sp == 2 && p.combine_cnt && !g_knobs.misc[6]) ? 22.0 : 30.0;
         if (sp > 1 && gain > cost) { full = T - R; split = sp; }
     }
+    // (Not kept, round 4: a stream-K cut of the last rounds - the last whole round and the partly filled one behind it dealt to
+    //  256 workgroups as equal runs of K-tiles, a run = tail piece of one tile + whole tiles + head piece of another, the two
+    //  pieces of a tile combined by the pair hand-off above; tools/experiments/r04_streamk_cut.patch, correct and bitwise
+    //  reproducible on 12 shapes.  Slower everywhere (profiles/r04_streamk_ab.txt): ESM wo 159 vs 138 us, fc2 440 vs 414,
+    //  21000-row fc2 314 vs 265, decoder down 601 vs 569.  The stream-K part runs at 2.47 us per k-tile instead of 1.6: runs start
+    //  at different k offsets, so the 32 workgroups of an XCD no longer walk K in step, nothing they stream is shared in that
+    //  XCD's L2 at the time it is needed, and 256 CUs x 64 KB per k-tile is 6.5 TB/s through the fabric - the kernel NEEDS
+    //  the >= 2x L2 reuse that tiles in k-lockstep give it.  Equal k-parts (the split above) keep the lockstep; unequal ones cannot.)
     const int tail = T - full;
     static const bool trace = getenv("OPUS_PP_TRACE") != nullptr;      // tuning aid: per-workgroup section times on stderr
     if (trace) {
