@@ -108,6 +108,9 @@ class Workload:
         from opus_pllm_amd.alphabet import batch_convert
         self.model, self.B, self.N_new, self.lengths = model, B, a.new_tokens, lengths
         self.sampler = (a.temperature, a.top_p, 1234) if a.temperature > 0 else None
+        # the workload the committed PMC passes were taken on (profiles/r04_pmc_traffic_b{64,1}.json): see roofline()
+        self.pmc_workload = (a.model == "llama3_8b" and a.new_tokens == 32 and self.sampler is None and not a.padded_encoder
+                             and B in (1, 64) and all(n == 512 for n in lengths))
         seqs = [synth.synth_protein(n, rank * B + i) for i, n in enumerate(lengths)]
         self.bucket_rows = None
         if not a.padded_encoder:      # token-packed encoder (default): the batch's tokens back to back, no padding, no buckets
@@ -325,11 +328,23 @@ def roofline(model, work, dev):
     # a GEMM class is HBM-bound when it ran below the MFMA ridge (FLOP per byte << 400): decode, projector at small M
     dom_hbm = dom in HBM_CLASSES or (by > 0 and fl / by < 200.0)
     res = block(ms, n, by, fl, dom_hbm)
+    # traffic: counters cannot be collected inside bench.py (rocprofv3 --pmc passes of THIS command, one counter set per pass:
+    # tools/prof_step.sh, summarised by tools/pmc_summary.py) - the committed summary of the last such passes is reported here,
+    # per launch of the dominant class, when it was taken on the workload this run measures
+    traffic, traffic_note = None, "no committed PMC summary for this workload (tools/prof_step.sh + tools/pmc_summary.py)"
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r04_pmc_traffic_b{work.B}.json")
+    if os.path.exists(pmc_file) and getattr(work, "pmc_workload", False):
+        try:
+            c = json.load(open(pmc_file))["classes"].get(dom)
+            if c and c.get("launches"):
+                traffic = c["fabric_bytes"] / c["launches"]
+                traffic_note = (f"L2<->fabric bytes per launch of {dom} (TCC_EA0 read requests, gfx950-corrected, + WRITE_SIZE; Infinity-Cache "
+                                f"hits are counted) from the committed rocprofv3 --pmc passes of this command, profiles/{os.path.basename(pmc_file)}: "
+                                f"{c['ratio']:.2f} x the algorithmic bytes of that pass; collected in separate passes, not in this run")
+        except (OSError, ValueError, KeyError):
+            pass
     res.update({"kernel": f"{dom} (largest summed duration of the step: {100.0 * ms / all_ms:.0f} % of kernel time)",
-                "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "traffic": None,
-                "traffic_note": "L2<->fabric bytes from rocprofv3 PMC passes of this command, per kernel class beside these "
-                                "algorithmic bytes, are in profiles/ (r03_pmc_traffic.json, tools/pmc_summary.py); counters cannot "
-                                "be collected inside bench.py",
+                "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "traffic": traffic, "traffic_note": traffic_note,
                 "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])},
                 "algorithmic_gb_per_step": {k: round(v[2] / 1e9, 4) for k, v in tot.items()},
                 "algorithmic_tflop_per_step": {k: round(v[3] / 1e12, 4) for k, v in tot.items() if v[3] > 0},
