@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 7
+#define OPUS_ABI_VERSION 8
 
 enum opus_status {
     OPUS_OK = 0,
@@ -240,6 +240,20 @@ int opus_check_error(opus_ctx *ctx, void *stream);
 int opus_beam_topk(opus_ctx *ctx, const float *d_run_scores, int32_t B, int32_t K, int32_t M, float *d_scores, int32_t *d_idx,
                    void *stream);
 int opus_kv_reorder(opus_ctx *ctx, const int32_t *d_src_rows, int32_t R, void *stream);
+/* Beam-sample (`num_beams` > 1 with temperature > 0: run_opus_ddp.py:126-129 passes both; _get_top_k_continuations' do_sample
+ * branch = torch.multinomial(softmax(accumulated), M), without replacement).  Per decoder row: log_softmax, then the warpers on
+ * the log-probabilities (temperature, top_k of opus_set_sampling_top_k, top_p); per batch row: M continuations drawn without
+ * replacement from softmax over the K rows' kept values + run_scores.  d_scores fp32 [B, M] = the accumulated log-probabilities of
+ * the draws, d_idx int32 [B, M] = k * dec_vocab + token, in the order drawn; entries beyond the continuations of non-zero
+ * probability are -inf / 0x7fffffff (torch.multinomial raises there: the caller should).  Draws come from a counter-based generator
+ * keyed by (seed, step, row, token): distributional parity, reproducible per seed.  d_logits NULL = this context's last step. */
+int opus_beam_sample_topk(opus_ctx *ctx, const float *d_logits, const float *d_run_scores, int32_t B, int32_t K, int32_t M,
+                          float temperature, float top_p, uint64_t seed, int32_t step, float *d_scores, int32_t *d_idx, void *stream);
+/* TopKLogitsWarper of this context's sampling paths (opus_generate_sample, opus_debug_sample, opus_beam_sample_topk), between the
+ * temperature and the nucleus: k > 0 keeps the k most probable tokens and whatever ties with the k-th; 0 (the state of a new
+ * context) = off.  transformers 4.46.3 - requirements.txt:20 of the reference - defaults GenerationConfig.top_k to 50 when it
+ * samples (transformers >= 5: None); the Python mirror's generate(top_k=...) defaults to 50 accordingly. */
+int opus_set_sampling_top_k(opus_ctx *ctx, int32_t k);
 
 /* fp32 logits [B, dec_vocab] of the most recent prefill / decode step (device copy on `stream`): the payload of the
  * optional logits all-gather of SURVEY 8e (ids are what eval/run_opus_ddp.py:138 gathers). */

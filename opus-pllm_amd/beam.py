@@ -2,9 +2,11 @@
 
 The reference forwards `num_beams` to transformers' GenerationMixin, whose `_beam_search` (generation/utils.py, the vectorised
 form of transformers >= 4.50; the pinned 4.46.3 keeps the same scores in a BeamSearchScorer heap) is restated here on numpy
-float32 arrays, step for step, for `do_sample=False`, `length_penalty=1.0`, `early_stopping=False` (the reference sets none of
-them: run_opus_ddp.py:126-132).  The O(K V) part of a step - log_softmax, + running scores, top-M over the K V continuations -
-runs on the device (opus_beam_topk); this class consumes those M = max(2, 1 + #eos) K candidates per batch row.
+float32 arrays, step for step, for `length_penalty=1.0`, `early_stopping=False` (the reference sets neither:
+run_opus_ddp.py:126-132).  The O(K V) part of a step - log_softmax, + running scores, and the M = max(2, 1 + #eos) K continuations
+per batch row: the best M (opus_beam_topk; `do_sample=False`) or M drawn without replacement after the warpers
+(opus_beam_sample_topk; beam-sample, temperature > 0) - runs on the device; this class consumes those M candidates, which
+`_beam_search` treats alike from there on (the first K of them may finish; the best K that did not stop run on).
 
     state = BeamState(B, K, max_new_tokens, eos_ids, pad_id, vocab)
     while True:
@@ -50,8 +52,8 @@ class BeamState:
         self.top_mask = np.arange(self.M) < K
 
     def step(self, topk_scores: np.ndarray, topk_idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray, bool]:
-        """topk_scores fp32 [B, M] descending, topk_idx int [B, M] = beam * vocab + token -> (next tokens int64 [B, K],
-        parent beam of every running beam int64 [B, K], done)."""
+        """topk_scores fp32 [B, M] (descending for beam search, in the order drawn for beam-sample), topk_idx int [B, M] =
+        beam * vocab + token -> (next tokens int64 [B, K], parent beam of every running beam int64 [B, K], done)."""
         B, K, M, cur = self.B, self.K, self.M, self.cur
         lp = topk_scores.astype(np.float32).reshape(B, M)
         idx = topk_idx.astype(np.int64).reshape(B, M)

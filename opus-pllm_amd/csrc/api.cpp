@@ -86,6 +86,8 @@ struct opus_ctx {
     int32_t *d_chosen;
     // sampling head (0 = greedy)
     float samp_temp = 0.f, samp_top_p = 1.f;
+    int samp_top_k = 0;                       // opus_set_sampling_top_k (0 = no TopKLogitsWarper)
+    float *d_bthr = nullptr, *d_blse = nullptr;   // beam-sample: keep threshold and log-sum-exp per decoder row
     int64_t gemm_ws_bytes = 0;
     half_t *d_xn, *d_qkv, *d_ctx, *d_act, *d_xln, *kc, *vc;
     float *cs_enc, *cs_dec, *cs_row;
@@ -214,6 +216,8 @@ static void carve(opus_ctx *c, char *base, size_t *total) {
     c->d_cand_i = k.take<int32_t>(B * ((size_t)g.dec_vocab + 64 * 4));
     c->d_cand_n = k.take<int32_t>(64 * B);
     c->d_zpart = k.take<float>(64 * B);
+    c->d_bthr = k.take<float>(B);
+    c->d_blse = k.take<float>(B);
     c->d_spart = k.take<float>(64 * B);
     c->d_seed = k.take<uint64_t>(2);
     c->d_chosen = k.take<int32_t>(B);
@@ -1158,8 +1162,8 @@ static int argmax(opus_ctx *c, hipStream_t s, int max_new, int n_eos, int pad_id
     const int32_t *chosen = nullptr;
     if (c->samp_temp > 0.f) {
         KL(KC_OTHER, 4.0 * 4 * c->cur_B * g.dec_vocab,
-           launch_sample_select(c->d_logits, c->cur_B, g.dec_vocab, c->samp_temp, c->samp_top_p, c->d_seed, c->d_step, c->d_pval,
-                                c->d_pidx, c->d_probs, c->d_cand_i, c->d_cand_n, c->d_zpart, c->d_spart, c->d_chosen, s));
+           launch_sample_select(c->d_logits, c->cur_B, g.dec_vocab, c->samp_temp, c->samp_top_p, c->samp_top_k, c->d_seed, c->d_step,
+                                c->d_pval, c->d_pidx, c->d_probs, c->d_cand_i, c->d_cand_n, c->d_zpart, c->d_spart, c->d_chosen, nullptr, s));
         chosen = c->d_chosen;
     } else {
         KL(KC_OTHER, 4.0 * c->cur_B * g.dec_vocab, launch_argmax_partial(c->d_logits, c->cur_B, g.dec_vocab, c->d_pval, c->d_pidx, s));
@@ -1288,8 +1292,8 @@ extern "C" int opus_debug_sample(opus_ctx *c, const float *d_logits, int32_t B, 
     hipStream_t s = (hipStream_t)stream;
     HIPC(hipMemcpyAsync(c->d_seed, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(c->d_plan, &step, sizeof(step), hipMemcpyHostToDevice, s));
-    HIPC(launch_sample_select(d_logits, B, c->cfg.dec_vocab, temperature, top_p, c->d_seed, c->d_plan, c->d_pval, c->d_pidx,
-                              c->d_probs, c->d_cand_i, c->d_cand_n, c->d_zpart, c->d_spart, d_tokens, s));
+    HIPC(launch_sample_select(d_logits, B, c->cfg.dec_vocab, temperature, top_p, c->samp_top_k, c->d_seed, c->d_plan, c->d_pval, c->d_pidx,
+                              c->d_probs, c->d_cand_i, c->d_cand_n, c->d_zpart, c->d_spart, d_tokens, nullptr, s));
     HIPC(hipStreamSynchronize(s));   // seed / step are host temporaries
     return OPUS_OK;
 }
@@ -1400,6 +1404,42 @@ extern "C" int opus_beam_topk(opus_ctx *c, const float *d_run_scores, int32_t B,
     c->phase = PH_DECODE;
     KL(KC_OTHER, 12.0 * c->cur_B * c->cfg.dec_vocab,
        launch_beam_topk(c->d_logits, d_run_scores, B, K, c->cfg.dec_vocab, M, c->d_zpart, d_scores, d_idx, s));
+    return OPUS_OK;
+}
+
+// Beam-sample step (do_sample with num_beams > 1; transformers _get_top_k_continuations, do_sample branch): the M
+// continuations of every batch row drawn WITHOUT replacement from softmax over the K V accumulated log-probabilities, after
+// log_softmax and the warpers (temperature, top_k of opus_set_sampling_top_k, top_p) on each of the K rows - scores fp32
+// [B, M] (the accumulated log-probabilities of the drawn continuations) and flat indices k V + token int32 [B, M] in the order
+// drawn; entries beyond the continuations of non-zero probability are -inf / 0x7fffffff.  d_logits NULL: the last step's.
+extern "C" int opus_beam_sample_topk(opus_ctx *c, const float *d_logits, const float *d_run_scores, int32_t B, int32_t K, int32_t M,
+                                     float temperature, float top_p, uint64_t seed, int32_t step, float *d_scores, int32_t *d_idx,
+                                     void *stream) {
+    if (!c || !d_run_scores || !d_scores || !d_idx) return fail(OPUS_EBADARG, "beam_sample_topk: null pointer");
+    if (!d_logits && !c->prefilled) return fail(OPUS_ESTATE, "beam_sample_topk before prefill");
+    if (B < 1 || K < 1 || B * K > c->cfg.max_batch || (!d_logits && B * K != c->cur_B))
+        return fail(OPUS_ESHAPE, "beam_sample_topk: B=%d x K=%d rows (the last step had %d, the context holds %d)", B, K, c->cur_B, c->cfg.max_batch);
+    if (M < 1 || M > 16) return fail(OPUS_ESHAPE, "beam_sample_topk: 1 <= M <= 16 candidates per row (got %d)", M);
+    if (!(temperature > 0.f) || top_p <= 0.f || top_p > 1.f) return fail(OPUS_EBADARG, "beam_sample_topk: temperature > 0, 0 < top_p <= 1");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const float *lg = d_logits ? d_logits : c->d_logits;
+    const int V = c->cfg.dec_vocab, R = B * K;
+    c->phase = PH_DECODE;
+    KL(KC_OTHER, 4.0 * 4 * R * V,
+       launch_sample_select(lg, R, V, temperature, top_p, c->samp_top_k, nullptr, nullptr, c->d_pval, c->d_pidx, c->d_probs, c->d_cand_i,
+                            c->d_cand_n, c->d_zpart, c->d_spart, nullptr, c->d_bthr, s));
+    KL(KC_OTHER, 12.0 * R * V,
+       launch_beam_sample(lg, d_run_scores, B, K, V, M, temperature, c->d_pval, c->d_bthr, seed, step, c->d_blse, d_scores, d_idx, s));
+    return OPUS_OK;
+}
+
+// TopKLogitsWarper of the sampling paths of this context (opus_generate_sample, opus_debug_sample, opus_beam_sample_topk):
+// k > 0 keeps the k most probable tokens (and ties with the k-th) before the nucleus; 0 = off.  transformers 4.46.3 - the
+// reference's pin - defaults GenerationConfig.top_k to 50 whenever it samples; the Python mirror sets that default.
+extern "C" int opus_set_sampling_top_k(opus_ctx *c, int32_t k) {
+    if (!c || k < 0) return fail(OPUS_EBADARG, "set_sampling_top_k: k >= 0");
+    c->samp_top_k = k;
     return OPUS_OK;
 }
 

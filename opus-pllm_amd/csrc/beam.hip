@@ -97,6 +97,95 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float *__restrict_
     }
 }
 
+// Beam-sample (do_sample with num_beams > 1): _get_top_k_continuations draws the M continuations of a batch row with
+// torch.multinomial(softmax(accumulated), M) - without replacement - from the K V accumulated log-probabilities
+//   a(k, v) = (logits[b K + k][v] - lse[b K + k]) / T + run[b K + k]     for the tokens the warpers keep, -inf for the others
+// (log_softmax first, then TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper on the log-probabilities: the kept set
+// of a row is the sampling head's, p = exp(l / T - max / T) > thr[row]).  Drawing without replacement from softmax(a) is taking
+// the M largest of a + g with g i.i.d. standard Gumbel (the order of the keys is the order of the draws): the same per-thread
+// sorted lists and block arg-max rounds as beam_topk_kernel, on the keys.  g comes from a counter-based generator keyed by
+// (seed, step, row, token): a given seed reproduces its draws; parity with the reference is distributional.
+// out_s = a of the drawn continuations (NOT the keys), out_i = k V + v, in the order drawn.
+__global__ __launch_bounds__(256) void beam_sample_kernel(const float *__restrict__ logits, const float *__restrict__ lse,
+                                                          const float *__restrict__ run, const float *__restrict__ pmax,
+                                                          const float *__restrict__ thr, float inv_temp, uint64_t seed, int step,
+                                                          int K, int V, int M, float *__restrict__ out_s, int32_t *__restrict__ out_i) {
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    __shared__ int s_who[256];
+    __shared__ float s_a[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float bk[BEAM_MAXM], ba[BEAM_MAXM];
+    int bi[BEAM_MAXM];
+#pragma unroll
+    for (int j = 0; j < BEAM_MAXM; ++j) { bk[j] = -INFINITY; ba[j] = -INFINITY; bi[j] = 0x7fffffff; }
+    for (int k = 0; k < K; ++k) {
+        const int r = b * K + k;
+        const float *row = logits + (int64_t)r * V;
+        float gmax = pmax[r * APART];
+        for (int q = 1; q < APART; ++q) gmax = fmaxf(gmax, pmax[r * APART + q]);
+        gmax *= inv_temp;                                            // (the expression of sample_stage1_kernel: the same p)
+        const float off = lse[r], add = run[r], th = thr[r];
+        const uint64_t h0 = splitmix64(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(r + 1)) ^ ((uint64_t)(step + 1) << 32));
+        for (int v = tid; v < V; v += 256) {
+            const float l = row[v];
+            const float p = __expf(l * inv_temp - gmax);
+            if (!(p > th)) continue;
+            const float a = (l - off) * inv_temp + add;
+            const uint64_t h = splitmix64(h0 + 0xD1B54A32D192ED03ull * (uint64_t)(v + 1));
+            const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+            const float key = a - __logf(-__logf(u));
+            const int id = k * V + v;
+            if (key > bk[BEAM_MAXM - 1] || (key == bk[BEAM_MAXM - 1] && id < bi[BEAM_MAXM - 1])) {
+                float ck = key, ca = a;
+                int ci = id;
+#pragma unroll
+                for (int j = 0; j < BEAM_MAXM; ++j) {
+                    const bool better = ck > bk[j] || (ck == bk[j] && ci < bi[j]);
+                    const float tk = better ? bk[j] : ck, ta = better ? ba[j] : ca;
+                    const int ti = better ? bi[j] : ci;
+                    bk[j] = better ? ck : bk[j];
+                    ba[j] = better ? ca : ba[j];
+                    bi[j] = better ? ci : bi[j];
+                    ck = tk; ca = ta; ci = ti;
+                }
+            }
+        }
+    }
+    int head = 0;
+    for (int r = 0; r < M; ++r) {
+        float hv = -INFINITY, ha = -INFINITY;
+        int hi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < BEAM_MAXM; ++j)
+            if (j == head) { hv = bk[j]; ha = ba[j]; hi = bi[j]; }
+        s_v[tid] = hv; s_i[tid] = hi; s_who[tid] = tid; s_a[tid] = ha;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float v = s_v[tid + o];
+                const int i = s_i[tid + o];
+                if (v > s_v[tid] || (v == s_v[tid] && i < s_i[tid])) { s_v[tid] = v; s_i[tid] = i; s_who[tid] = s_who[tid + o]; s_a[tid] = s_a[tid + o]; }
+            }
+            __syncthreads();
+        }
+        // (fewer than M kept continuations with a non-zero probability: the tail is -inf / index 0x7fffffff; the host refuses the step
+        //  as torch.multinomial refuses to draw more samples than there are non-zero categories)
+        if (tid == 0) { out_s[b * M + r] = s_a[0]; out_i[b * M + r] = s_i[0]; }
+        if (s_who[0] == tid) ++head;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_beam_sample(const float *logits, const float *run, int B, int K, int V, int M, float temperature, const float *pmax,
+                              const float *thr, uint64_t seed, int step, float *lse, float *out_s, int32_t *out_i, hipStream_t s) {
+    if (M < 1 || M > BEAM_MAXM || K < 1 || (int64_t)K * V >= 0x7fffffff || !(temperature > 0.f)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(beam_lse_kernel, dim3(B * K), dim3(256), 0, s, logits, V, lse);
+    hipLaunchKernelGGL(beam_sample_kernel, dim3(B), dim3(256), 0, s, logits, lse, run, pmax, thr, 1.0f / temperature, seed, step, K, V, M,
+                       out_s, out_i);
+    return hipGetLastError();
+}
+
 hipError_t launch_beam_topk(const float *logits, const float *run, int B, int K, int V, int M, float *lse, float *out_s,
                             int32_t *out_i, hipStream_t s) {
     if (M < 1 || M > BEAM_MAXM || K < 1 || (int64_t)K * V >= 0x7fffffff) return hipErrorInvalidValue;

@@ -296,9 +296,17 @@ hipError_t launch_splice_plan(const int64_t *ids, const uint8_t *mask, int B, in
 hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, int Tt, const half_t *prot,
                               int n_tok, int H, int V, const half_t *emb, const int32_t *plan, int Tout,
                               int left_pad, half_t *out, uint8_t *mask_out, int32_t *pos_out, hipStream_t s);
-hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, const uint64_t *seed,
+// (thr_out != nullptr: no draw; the rows' keep thresholds on p = exp(l / T - max / T) are written there - beam-sample)
+hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, int top_k, const uint64_t *seed,
                                 const int32_t *step, float *pmax, int32_t *pidx, float *cand_p, int32_t *cand_i,
-                                int32_t *cand_n, float *zpart, float *spart, int32_t *chosen, hipStream_t s);
+                                int32_t *cand_n, float *zpart, float *spart, int32_t *chosen, float *thr_out, hipStream_t s);
+constexpr int APART = 64;     // parts a logits row is cut into by argmax_partial / sample_stage1 (pmax[row * APART + part])
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
 hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, const int32_t *chosen, int B, const int32_t *eos, int n_eos, int pad_id,
                               int32_t *finished, int32_t *out_ids, int max_new, const int32_t *step,
                               int32_t *next_tok, int32_t *n_unfinished, const int32_t *stop, int n_stop, hipStream_t s);
@@ -306,6 +314,10 @@ hipError_t launch_step_advance(int32_t *step, hipStream_t s);
 // beam.hip: best M of the K V continuations per batch row (log_softmax + running scores), cache rows of the surviving beams
 hipError_t launch_beam_topk(const float *logits, const float *run, int B, int K, int V, int M, float *lse, float *out_s,
                             int32_t *out_i, hipStream_t s);
+// beam-sample: M continuations per batch row drawn without replacement from softmax over the K filtered rows' accumulated
+// log-probabilities (thr: launch_sample_select's thresholds, pmax: its per-part maxima), in the order drawn
+hipError_t launch_beam_sample(const float *logits, const float *run, int B, int K, int V, int M, float temperature, const float *pmax,
+                              const float *thr, uint64_t seed, int step, float *lse, float *out_s, int32_t *out_i, hipStream_t s);
 hipError_t launch_kv_gather_rows(const half_t *src, half_t *dst, const int32_t *idx, int R, int64_t row_halfs, hipStream_t s);
 hipError_t launch_upload_i32(const int32_t *h, int n, int32_t *dst, hipStream_t s);   // host ints -> device through kernel arguments
 hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kstart, hipStream_t s);

@@ -269,12 +269,7 @@ hipError_t launch_take_last(const float *x, int B, int T, int H, float *out, hip
 
 // ------------------------------------------------------------------------------ synthetic fill
 // Bit-identical twin of opus-pllm_amd/synth.py::hash_normal (splitmix64 -> Irwin-Hall(4x16 bit)).
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
+// (splitmix64: common.h)
 __device__ __forceinline__ float synth_value(uint64_t seed, uint64_t i, float scale, float mean, int has_mean) {
     const uint64_t z = splitmix64(i + seed);
     const int sum = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)(z >> 48);
@@ -474,7 +469,7 @@ hipError_t launch_splice_fill(const int64_t *ids, const uint8_t *mask, int B, in
 
 // ------------------------------------------------------------------------------ greedy step (G1)
 // Stage 1: APART partial (max, lowest index) per row, float4 loads, many workgroups per row.
-constexpr int APART = 64;
+// (APART = 64 parts per logits row: common.h)
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const float *__restrict__ logits, int V,
                                                              float *__restrict__ pval, int32_t *__restrict__ pidx) {
     __shared__ float s_v[256];
@@ -581,6 +576,9 @@ hipError_t launch_argmax_step(const float *pval, const int32_t *pidx, const int3
 //   draw u from a counter-based generator (seed, row, step) and invert the CDF of the kept set in index order.
 // The nucleus threshold is found by bisection on the probability value (40 halvings: narrower than fp32
 // spacing), every pass a fixed-order block reduction, so a (seed, row, step) triple always gives the same token.
+// top_k > 0 (transformers 4.46.3, the reference's pin, defaults GenerationConfig.top_k to 50; TopKLogitsWarper runs between
+// the temperature and the nucleus): only the k most probable tokens - and everything tied with the k-th - enter the nucleus
+// computation, whose mass Z is then theirs alone.  The k-th value is found by the same kind of bisection (a count instead of a sum).
 __device__ __forceinline__ float block_sum256(float v, float *scratch) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -649,11 +647,13 @@ __global__ __launch_bounds__(256) void sample_stage1_kernel(const float *__restr
 
 // Stage 2 (one workgroup per row): nucleus threshold by bisection over the candidates, then the draw.
 constexpr int SAMPLE_LDS_CAP = 6144;
-__global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, const uint64_t *__restrict__ seed_p,
+// thr_out != nullptr: no draw - the row's keep threshold (a token is kept iff its p = exp(l / T - max / T) exceeds it) is written
+// there instead (beam-sample: beam.hip draws M continuations per batch row from the K filtered rows jointly).
+__global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, int top_k, const uint64_t *__restrict__ seed_p,
                                                             const int32_t *__restrict__ step, const float *__restrict__ cand_p,
                                                             const int32_t *__restrict__ cand_i, const int32_t *__restrict__ cand_n,
                                                             const float *__restrict__ zpart, const float *__restrict__ spart,
-                                                            int32_t *__restrict__ chosen) {
+                                                            int32_t *__restrict__ chosen, float *__restrict__ thr_out) {
     __shared__ float scratch[4];
     __shared__ float s_pref[257];
     __shared__ int s_off[APART + 1];
@@ -668,7 +668,6 @@ __global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, 
     const int nc = s_off[APART];
     float Z = 0.f, S0 = 0.f;
     for (int k = 0; k < APART; ++k) { Z += zpart[b * APART + k]; S0 += spart[b * APART + k]; }   // fixed order
-    const float cut = (1.0f - top_p) * Z;
     // candidate c (global order = index order) lives at part k, slot c - s_off[k]
     auto cand = [&](int c, int &idx) -> float {
         int k = 0;
@@ -682,17 +681,46 @@ __global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, 
         for (int c = tid; c < nc; c += 256) { int id; s_p[c] = cand(c, id); }
     __syncthreads();
     auto pval = [&](int c) -> float { int id; return in_lds ? s_p[c] : cand(c, id); };
-    // bisection: S_le(x) = S0 + sum of candidates <= x ; invariant S_le(lo) <= cut < S_le(hi)
+    // top-k: lo_k < (k-th largest p) <= hi_k, i.e. count(p > lo_k) >= k > count(p > hi_k); the tokens that stay are p > lo_k.
+    // Every token that can survive the nucleus is a stage-1 candidate (see there), so with fewer than k candidates all of them
+    // stay; the other members of the top-k set then carry < k (1 - top_p) / V of the mass and are left out of Z.
+    float lo_k = 0.f;
+    if (top_k > 0 && top_k < V) {
+        if (nc > top_k) {
+            float hi_k = 1.0f;
+            for (int it = 0; it < 40; ++it) {
+                const float mid = 0.5f * (lo_k + hi_k);
+                float n = 0.f;
+                for (int c = tid; c < nc; c += 256) n += pval(c) > mid ? 1.f : 0.f;
+                n = block_sum256(n, scratch);                         // (counts <= 2^24: exact in fp32)
+                if (n >= (float)top_k) lo_k = mid; else hi_k = mid;
+            }
+        }
+        float z = 0.f;
+        for (int c = tid; c < nc; c += 256) {
+            const float p = pval(c);
+            z += p > lo_k ? p : 0.f;
+        }
+        Z = block_sum256(z, scratch);
+        S0 = 0.f;
+    }
+    const float cut = (1.0f - top_p) * Z;
+    // bisection: S_le(x) = S0 + sum of the (top-k) candidates <= x ; invariant S_le(lo) <= cut < S_le(hi)
     float lo = 0.f, hi = 1.0f;
     for (int it = 0; it < 40; ++it) {
         const float mid = 0.5f * (lo + hi);
         float s = 0.f;
         for (int c = tid; c < nc; c += 256) {
             const float p = pval(c);
-            s += p <= mid ? p : 0.f;
+            s += (p <= mid && p > lo_k) ? p : 0.f;
         }
         s = S0 + block_sum256(s, scratch);
         if (s > cut) hi = mid; else lo = mid;
+    }
+    lo = fmaxf(lo, lo_k);
+    if (thr_out) {
+        if (tid == 0) thr_out[b] = lo;
+        return;
     }
     // kept = candidates with p > lo; CDF inversion in index order over contiguous chunks of the candidate list
     const int cper = (nc + 255) / 256;
@@ -727,14 +755,14 @@ __global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, 
     }
 }
 
-hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, const uint64_t *seed,
+hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, int top_k, const uint64_t *seed,
                                 const int32_t *step, float *pmax, int32_t *pidx, float *cand_p, int32_t *cand_i,
-                                int32_t *cand_n, float *zpart, float *spart, int32_t *chosen, hipStream_t s) {
+                                int32_t *cand_n, float *zpart, float *spart, int32_t *chosen, float *thr_out, hipStream_t s) {
     hipLaunchKernelGGL(argmax_partial_kernel, dim3(APART, B), dim3(256), 0, s, logits, V, pmax, pidx);
     hipLaunchKernelGGL(sample_stage1_kernel, dim3(APART, B), dim3(256), 0, s, logits, V, 1.0f / temperature, top_p, pmax, cand_p,
                        cand_i, cand_n, zpart, spart);
-    hipLaunchKernelGGL(sample_stage2_kernel, dim3(B), dim3(256), 0, s, V, top_p, seed, step, cand_p, cand_i, cand_n, zpart, spart,
-                       chosen);
+    hipLaunchKernelGGL(sample_stage2_kernel, dim3(B), dim3(256), 0, s, V, top_p, top_k, seed, step, cand_p, cand_i, cand_n, zpart,
+                       spart, chosen, thr_out);
     return hipGetLastError();
 }
 

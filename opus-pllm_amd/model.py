@@ -305,6 +305,7 @@ class OpusLlamaForCausalLM:
         do_sample = bool(kwargs.pop("do_sample", False))
         temperature = kwargs.pop("temperature", None)
         top_p = kwargs.pop("top_p", None)
+        top_k = kwargs.pop("top_k", self.default_top_k)                  # (transformers 4.46.3: GenerationConfig.top_k = 50)
         seed = kwargs.pop("seed", None)
         num_beams = kwargs.pop("num_beams", 1)
         num_beams = 1 if num_beams is None else int(num_beams)
@@ -321,11 +322,12 @@ class OpusLlamaForCausalLM:
                 raise ValueError("`temperature` has to be a strictly positive float when do_sample=True")
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # follows torch.manual_seed
-            sampler = (t, 1.0 if top_p is None else float(top_p), int(seed))
+            k = 0 if top_k is None else int(top_k)
+            if k < 0:
+                raise ValueError("`top_k` has to be a non-negative integer (0 / None: no top-k filtering)")
+            sampler = (t, 1.0 if top_p is None else float(top_p), int(seed), k)
         if num_beams < 1:
             raise ValueError("`num_beams` has to be an integer strictly greater than 0")
-        if num_beams > 1 and do_sample:
-            raise NotImplementedError("beam-sample decoding (num_beams > 1 with do_sample=True) is not built: use temperature 0")
         beam_pad = pad_id                                      # (HF's beam fill value distinguishes None / 0 from an id)
         if pad_id is None:
             pad_id = eos[0] if eos else 0
@@ -340,15 +342,26 @@ class OpusLlamaForCausalLM:
                                 device=self.device)
             embeds, mask, _ = self._splice(inputs, attention_mask, dummy, True)
         if num_beams > 1:
-            return self._beam_search(embeds, mask, max_new, eos, beam_pad, num_beams)
+            return self._beam_search(embeds, mask, max_new, eos, beam_pad, num_beams, sampler)
         return self._greedy(embeds, mask, max_new, eos, int(pad_id), sampler)
 
-    def _beam_search(self, embeds, mask, max_new, eos, pad_id, K) -> torch.Tensor:
-        """transformers GenerationMixin._beam_search for do_sample=False (what run_opus_ddp.py:129,158 reaches with temperature 0
-        and --num_beams K): B x K decoder rows, per step the device scores the K V continuations of every batch row
-        (opus_beam_topk) and permutes the KV cache rows of the surviving beams (opus_kv_reorder); the host keeps the O(K)
-        bookkeeping (beam.BeamState).  Returns the best finished sequence of every row [B, n] (rows that stopped earlier are
-        filled as HF fills them)."""
+    # TopKLogitsWarper of the sampling paths.  The reference pins transformers 4.46.3 (requirements.txt:20), whose
+    # GenerationConfig.top_k defaults to 50 whenever it samples (transformers >= 5 defaults to None); the reference's drivers never
+    # set it (run_opus_ddp.py:126-132), so 50 is what its sampling runs with.  generate(top_k=...) overrides per call; 0 / None = off.
+    default_top_k = 50
+
+    def _set_top_k(self, k: int) -> None:
+        if k != getattr(self, "_top_k", 0):
+            _cabi.check(self._lib.opus_set_sampling_top_k(self._ctx, int(k)))
+            self._top_k = int(k)
+
+    def _beam_search(self, embeds, mask, max_new, eos, pad_id, K, sampler=None) -> torch.Tensor:
+        """transformers GenerationMixin._beam_search (what run_opus_ddp.py:129,158 reaches with --num_beams K): B x K decoder rows,
+        per step the device picks the M continuations of every batch row out of the K V - the best M by accumulated log-probability
+        (opus_beam_topk; temperature 0) or, with `sampler` (temperature > 0: beam-sample), M drawn without replacement after the
+        warpers (opus_beam_sample_topk) - and permutes the KV cache rows of the surviving beams (opus_kv_reorder); the host keeps
+        the O(K) bookkeeping (beam.BeamState).  Returns the best finished sequence of every row [B, n] (rows that stopped
+        earlier are filled as HF fills them)."""
         from .beam import BeamState
         B, T, _ = embeds.shape
         cfg = self.cfg
@@ -370,10 +383,23 @@ class OpusLlamaForCausalLM:
             d_ix = torch.empty((B, M), dtype=torch.int32, device=self.device)
             ident = np.tile(np.arange(K, dtype=np.int64), (B, 1))
             base = (np.arange(B, dtype=np.int64) * K)[:, None]
+            if sampler is not None:
+                self._set_top_k(sampler[3] if len(sampler) > 3 else self.default_top_k)
             while True:
                 d_run.copy_(torch.from_numpy(state.running_scores.reshape(-1)), non_blocking=True)
-                _cabi.check(self._lib.opus_beam_topk(self._ctx, d_run.data_ptr(), B, K, M, d_sc.data_ptr(), d_ix.data_ptr(), s))
+                if sampler is None:
+                    _cabi.check(self._lib.opus_beam_topk(self._ctx, d_run.data_ptr(), B, K, M, d_sc.data_ptr(), d_ix.data_ptr(), s))
+                else:
+                    _cabi.check(self._lib.opus_beam_sample_topk(self._ctx, None, d_run.data_ptr(), B, K, M, sampler[0], sampler[1],
+                                                                sampler[2], state.cur, d_sc.data_ptr(), d_ix.data_ptr(), s))
                 sc, ix = d_sc.cpu().numpy(), d_ix.cpu().numpy()         # (synchronises this stream)
+                # (fp32 softmax gives exactly zero below exp(-103.97): continuations that far under the row's best - filtered ones,
+                #  those of dead beams at -1e9 - are the "non-negative categories" torch.multinomial finds too few of)
+                if sampler is not None and ((ix == 0x7fffffff) | (sc < sc.max(axis=1, keepdims=True) - 103.0)).any():
+                    self._leave()
+                    raise RuntimeError("invalid multinomial distribution (with replacement=False, not enough non-negative category "
+                                       f"to sample): beam-sample draws {M} continuations per row, the temperature / top_k / top_p "
+                                       "filters left fewer")        # (torch.multinomial's message: what the reference raises here)
                 tok, src, done = state.step(sc, ix)
                 if done:
                     break
@@ -412,6 +438,8 @@ class OpusLlamaForCausalLM:
             out.fill_(pad_id)
             n_out = C.c_int32(0)
             eos_arr = (C.c_int32 * max(1, len(eos)))(*eos)
+            if sampler is not None:
+                self._set_top_k(sampler[3] if len(sampler) > 3 else self.default_top_k)
             if sampler is None:
                 _cabi.check(self._lib.opus_generate_greedy(self._ctx, embeds.data_ptr(), mask.data_ptr(), B, T, max_new,
                                                            eos_arr, len(eos), pad_id, out.data_ptr(), C.byref(n_out), s))

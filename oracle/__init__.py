@@ -23,5 +23,5 @@ from .llama import llama_forward, greedy_decode, decoder_forward_fn, KVCache  # 
 from .opt import opt_forward  # noqa: F401
 from .lora import lora_merge  # noqa: F401
 from .pipeline import OraclePipeline  # noqa: F401
-from .sampling import sampling_distribution  # noqa: F401
+from .sampling import beam_sample_distribution, sampling_distribution  # noqa: F401
 from .beam import beam_search  # noqa: F401

@@ -532,8 +532,19 @@ def test_generate_beam_golden(dev, gold, gold_dir):
     assert torch.equal(model.generate(ids, seqs, **kw), out)
     greedy = model.generate(ids, seqs, attention_mask=mask, pad_token_id=pad, do_sample=False, max_new_tokens=N)
     assert np.array_equal(greedy.cpu().numpy(), base["free_ids"][:, :N])
-    with pytest.raises(NotImplementedError):
-        model.generate(ids, seqs, attention_mask=mask, do_sample=True, temperature=0.5, num_beams=2, max_new_tokens=4)
+    # beam-sample (temperature > 0 with num_beams > 1): a seed reproduces its hypotheses, another seed gives others; with the
+    # reference's own sampling defaults (temperature 0.1, top_p 0.7) the nucleus holds fewer than the M = 2 K continuations a step
+    # draws, and torch.multinomial - hence the reference - raises: so does this
+    skw = dict(attention_mask=mask, pad_token_id=pad, do_sample=True, temperature=1.5, top_p=0.98, num_beams=2, max_new_tokens=6)
+    s1 = model.generate(ids, seqs, seed=3, **skw)
+    s2 = model.generate(ids, seqs, seed=3, **skw)
+    s3 = model.generate(ids, seqs, seed=4, **skw)
+    assert s1.shape[0] == 3 and 1 <= s1.shape[1] <= 6 and torch.equal(s1, s2)
+    assert s3.shape != s1.shape or not torch.equal(s1, s3)
+    assert int(s1.min()) >= 0 and int(s1.max()) < cfg.dec_vocab
+    with pytest.raises(RuntimeError, match="invalid multinomial distribution"):
+        model.generate(ids, seqs, attention_mask=mask, do_sample=True, temperature=0.1, top_p=0.7, num_beams=2, max_new_tokens=4)
+    assert torch.equal(model.generate(ids, seqs, **kw), out)       # (and the context is usable after the refusal)
     with pytest.raises(_cabi.OpusError):
         model.generate(ids, seqs, attention_mask=mask, num_beams=5, max_new_tokens=4)      # 15 rows > max_batch
     with pytest.raises(ValueError):
@@ -574,8 +585,8 @@ def test_generate_api_errors(micro):
         model.generate(ids, ["ACD"], inputs_embeds=torch.zeros(1))
     with pytest.raises(NotImplementedError):
         model.encode_seq2embedding([1, 2, 3])
-    with pytest.raises(NotImplementedError):                   # beam-sample decoding is refused; beam search is built
-        model.generate(ids, ["ACD"], num_beams=4, do_sample=True, temperature=0.7, max_new_tokens=4)
+    with pytest.raises(ValueError):
+        model.generate(ids, ["ACD"], do_sample=True, temperature=0.7, top_k=-1)
     out = model.generate(ids, ["ACD"], num_beams=4, max_new_tokens=4)       # 1 x 4 rows fit max_batch = 8
     assert out.shape == (1, 4)
     with pytest.raises(ValueError):
@@ -594,23 +605,85 @@ def test_sampling_head_matches_hf_distribution(micro, dev):
     lib = _cabi.lib()
     V, B = cfg.dec_vocab, 8
     g = torch.Generator().manual_seed(5)
-    base = torch.randn(1, V, generator=g) * 2.0
-    logits = base.repeat(B, 1).to(dev)
-    for temperature, top_p in ((0.7, 0.7), (1.0, 0.9), (0.1, 0.7)):
-        ref = oracle.sampling_distribution(base, temperature, top_p)[0]
+    base0 = torch.randn(1, V, generator=g) * 2.0
+    tied = base0.clone()
+    tied[0, 11] = tied[0, 3] = tied[0].topk(5)[0][-1]                # a three-way tie at the 5th value: TopKLogitsWarper keeps all of it
+    # (top_k 0: no TopKLogitsWarper, transformers >= 5's default; > 0: between temperature and nucleus - 4.46.3 defaults to 50.
+    #  The tie is tested without a nucleus: where the nucleus cut falls inside a tie HF keeps as many of the tied tokens as its
+    #  sort happened to put last, this head keeps or drops them together.)
+    for temperature, top_p, top_k, base in ((0.7, 0.7, 0, base0), (1.0, 0.9, 0, base0), (0.1, 0.7, 0, base0), (1.0, 0.9, 50, base0),
+                                            (1.5, 1.0, 5, tied), (2.0, 0.8, 20, base0), (1.0, 1.0, 1, base0)):
+        logits = base.repeat(B, 1).to(dev)
+        model._set_top_k(top_k)
+        ref = oracle.sampling_distribution(base, temperature, top_p, top_k)[0]
         counts = torch.zeros(V)
         toks = torch.empty(B, dtype=torch.int32, device=dev)
         for step in range(400):
             _cabi.check(lib.opus_debug_sample(model._ctx, logits.data_ptr(), B, temperature, top_p, 1234, step, toks.data_ptr(), None))
             counts += torch.bincount(toks.cpu().long(), minlength=V).float()
         freq = counts / counts.sum()
-        assert float(freq[ref == 0].sum()) == 0.0, (temperature, top_p)            # nothing outside the nucleus
-        assert float((freq - ref).abs().sum()) / 2 < 0.05, (temperature, top_p, freq.topk(5), ref.topk(5))
+        assert float(freq[ref == 0].sum()) == 0.0, (temperature, top_p, top_k)     # nothing outside the kept set
+        assert float((freq - ref).abs().sum()) / 2 < 0.05, (temperature, top_p, top_k, freq.topk(5), ref.topk(5))
+    model._set_top_k(0)
     a = torch.empty(B, dtype=torch.int32, device=dev)
     b = torch.empty(B, dtype=torch.int32, device=dev)
     _cabi.check(lib.opus_debug_sample(model._ctx, logits.data_ptr(), B, 0.7, 0.7, 99, 3, a.data_ptr(), None))
     _cabi.check(lib.opus_debug_sample(model._ctx, logits.data_ptr(), B, 0.7, 0.7, 99, 3, b.data_ptr(), None))
     assert torch.equal(a, b)
+
+
+def test_beam_sample_draws_match_hf_distribution(micro, dev):
+    """Beam-sample's device step (opus_beam_sample_topk) against the restated distribution (oracle.beam_sample_distribution:
+    log_softmax, warpers on the log-probabilities, + running scores, softmax over [K V]): M draws per batch row without
+    replacement.  Over 4 x 500 steps: every draw has non-zero probability, the M draws of a row are distinct, their scores are the
+    accumulated log-probabilities, the first draw follows the distribution and the second one the without-replacement law
+    sum_i p_i p_j / (1 - p_i) (total variation within 1.5 x the sampling noise of 2000 draws + 0.01); a (seed, step) pair reproduces its draws; dead beams (-1e9) are
+    never drawn, and when fewer than M continuations have non-zero probability the tail says so."""
+    import oracle
+    from opus_pllm_amd import _cabi
+    cfg, model, _ = micro
+    lib = _cabi.lib()
+    V, B, K, M = cfg.dec_vocab, 4, 2, 4
+    g = torch.Generator().manual_seed(9)
+    base = torch.randn(K, V, generator=g) * 2.0
+    logits = base.repeat(B, 1).to(dev).contiguous()                  # row b K + k
+    sc = torch.empty(B, M, dtype=torch.float32, device=dev)
+    ix = torch.empty(B, M, dtype=torch.int32, device=dev)
+
+    def draw(run, t, p, seed, step):
+        d_run = torch.tensor(run, dtype=torch.float32).repeat(B).to(dev)
+        _cabi.check(lib.opus_beam_sample_topk(model._ctx, logits.data_ptr(), d_run.data_ptr(), B, K, M, t, p, seed, step, sc.data_ptr(),
+                                              ix.data_ptr(), None))
+        return sc.cpu(), ix.cpu().long()
+
+    for t, p, k, run in ((1.0, 0.9, 0, [0.0, -0.7]), (1.5, 1.0, 6, [-0.3, 0.0]), (0.8, 0.95, 50, [0.0, -1.0e9])):
+        model._set_top_k(k)
+        ref = oracle.beam_sample_distribution(base, torch.tensor(run), t, p, k)
+        lp = torch.log(ref)                                              # accumulated log-probabilities up to the common normaliser
+        first, second = torch.zeros(K * V), torch.zeros(K * V)
+        for step in range(500):
+            s, i = draw(run, t, p, 77, step)
+            assert bool((ref[i] > 0).all()), (t, p, k)
+            assert all(len(set(r.tolist())) == M for r in i)
+            d = s - lp[i]                                                # the same offset (log Z) in every entry
+            assert float((d - d[0, 0]).abs().max()) < 2e-3
+            first += torch.bincount(i[:, 0], minlength=K * V).float()
+            second += torch.bincount(i[:, 1], minlength=K * V).float()
+        want2 = (ref[None, :] * ref[:, None] / (1 - ref[:, None]).clamp(min=1e-12))
+        want2.fill_diagonal_(0)
+        want2 = want2.sum(0)
+        # total variation against what 2000 draws of the distribution itself would show: E|f_i - p_i| = sqrt(2 p_i (1 - p_i) / (pi N))
+        for freq, want in ((first / first.sum(), ref), (second / second.sum(), want2)):
+            noise = 0.5 * float(torch.sqrt(2 * want * (1 - want) / (np.pi * float(first.sum()))).sum())
+            assert float((freq - want).abs().sum()) / 2 < 1.5 * noise + 0.01, (t, p, k, noise)
+    a = draw([0.0, -0.7], 1.0, 0.9, 5, 3)
+    b = draw([0.0, -0.7], 1.0, 0.9, 5, 3)
+    c = draw([0.0, -0.7], 1.0, 0.9, 6, 3)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0]) and not torch.equal(a[1], c[1])
+    model._set_top_k(2)                                                  # two kept tokens per beam, one live beam: 2 < M
+    s, i = draw([0.0, -1.0e9], 1.0, 1.0, 1, 0)
+    assert bool((i[:, :2] < V).all()) and bool((i[:, 2:] >= V).all())     # the live beam's two tokens, then dead-beam entries / fillers
+    model._set_top_k(0)
 
 
 def test_generate_with_sampling(micro, gold, gold_dir):

@@ -26,7 +26,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _cabi.lib()                          # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 7 and lib.opus_operand_dtype() == 0
+    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 8 and lib.opus_operand_dtype() == 0
     # pure host entry points that need no GPU
     cc = _cabi.CConfig.from_config(opa.llama3_8b())
     assert lib.opus_workspace_bytes(ctypes.byref(cc)) > 1 << 30
@@ -274,6 +274,58 @@ def test_beam_bookkeeping_matches_transformers(K, eos_mode, pad):
             lg = hf(inputs_embeds=full, attention_mask=fm, position_ids=pos).logits[:, -1].float()
         acc = torch.log_softmax(lg, -1).view(B, K, V) + torch.from_numpy(st.running_scores)[:, :, None]
         sc, ix = torch.topk(acc.view(B, K * V), st.M)
+        tok, src, done = st.step(sc.numpy(), ix.numpy())
+        if done:
+            break
+        seqs = torch.cat([seqs[torch.arange(B)[:, None], torch.from_numpy(src)], torch.from_numpy(tok)[:, :, None]], 2)
+    got = st.result()
+    assert got.shape == tuple(want.shape), (got.shape, want.shape)
+    assert np.array_equal(got, want.numpy()), (got, want)
+
+
+@pytest.mark.parametrize("K,temperature,top_p,top_k,eos_mode", [(2, 1.5, 1.0, 0, "none"), (3, 1.3, 0.95, 12, "one"), (2, 2.0, 1.0, 8, "two")])
+def test_beam_sample_bookkeeping_matches_transformers(K, temperature, top_p, top_k, eos_mode):
+    """Beam-sample (num_beams > 1 with temperature > 0: run_opus_ddp.py:126-129 forwards both): GenerationMixin._beam_search with
+    do_sample on the tiny CPU model of the test above against beam.BeamState fed with M continuations drawn the way
+    `_get_top_k_continuations` draws them - log_softmax, the warpers on the log-probabilities (oracle/sampling.py `_warp`),
+    + running scores, torch.multinomial over the flattened [K V] without replacement - from the same seed: ids equal.  (What the
+    device draws instead of torch.multinomial is checked distributionally in tests/test_gpu_parity.py.)"""
+    import torch
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from opus_pllm_amd.beam import BeamState
+    from oracle.sampling import _warp
+    torch.manual_seed(K * 11 + top_k)
+    V, H, B, T, N = 40, 32, 3, 5, 8
+    hf = LlamaForCausalLM(LlamaConfig(vocab_size=V, hidden_size=H, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4,
+                                      num_key_value_heads=2, max_position_embeddings=64)).eval()
+    emb = torch.randn(B, T, H)
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[2, :1] = 0
+    kw = dict(inputs_embeds=emb, attention_mask=mask, num_beams=K, do_sample=True, temperature=temperature, top_p=top_p,
+              top_k=top_k or None, max_new_tokens=N, use_cache=True, pad_token_id=0)
+    torch.manual_seed(99)
+    with torch.no_grad():
+        free = hf.generate(**kw, eos_token_id=None)
+    eos = {"none": [], "one": [int(free[0, 3])], "two": [int(free[0, 3]), int(free[1, 5])]}[eos_mode]
+    torch.manual_seed(123)
+    with torch.no_grad():
+        want = hf.generate(**kw, eos_token_id=eos or None)
+
+    st = BeamState(B, K, N, eos, 0, V)
+    tok_emb = hf.get_input_embeddings()
+    seqs = torch.zeros(B, K, 0, dtype=torch.long)
+    torch.manual_seed(123)
+    while True:
+        flat = seqs.reshape(B * K, -1)
+        full = torch.cat([emb.repeat_interleave(K, 0), tok_emb(flat)], 1)
+        fm = torch.cat([mask.repeat_interleave(K, 0), torch.ones(B * K, flat.shape[1], dtype=torch.long)], 1)
+        pos = (fm.cumsum(-1) - 1).clamp(min=0)
+        with torch.no_grad():
+            lg = hf(inputs_embeds=full, attention_mask=fm, position_ids=pos).logits[:, -1].float()
+        lp = _warp(torch.log_softmax(lg, -1) / temperature, top_p, top_k)
+        acc = (lp.view(B, K, V) + torch.from_numpy(st.running_scores)[:, :, None]).view(B, K * V)
+        ix = torch.multinomial(torch.softmax(acc, -1), st.M)            # (in the order drawn: not sorted)
+        sc = torch.gather(acc, 1, ix)
         tok, src, done = st.step(sc.numpy(), ix.numpy())
         if done:
             break

@@ -168,6 +168,12 @@ def test_sampling_distribution_restates_hf_warpers():
     for t, p in ((0.1, 0.7), (0.7, 0.7), (1.3, 0.95)):
         hf = TopPLogitsWarper(p)(None, TemperatureLogitsWarper(t)(None, logits)).softmax(-1)
         assert torch.allclose(oracle.sampling_distribution(logits, t, p), hf, atol=1e-7)
+    # with top-k between the two (transformers 4.46.3, the reference's pin, defaults GenerationConfig.top_k to 50 when it samples)
+    from transformers.generation.logits_process import TopKLogitsWarper
+    logits[0, 7] = logits[0, 3]                                          # a tie: TopKLogitsWarper keeps everything tied with the k-th
+    for t, p, k in ((0.7, 0.7, 50), (1.3, 0.95, 5), (2.0, 1.0, 20), (1.0, 0.9, 1), (1.0, 0.8, 400)):
+        hf = TopPLogitsWarper(p)(None, TopKLogitsWarper(k)(None, TemperatureLogitsWarper(t)(None, logits))).softmax(-1)
+        assert torch.allclose(oracle.sampling_distribution(logits, t, p, k), hf, atol=1e-7), (t, p, k)
 
 
 @pytest.mark.parametrize("tag,preset", [("generate_micro_opt", "micro_opt"), ("generate_micro_opt_relu", "micro_opt_relu"),
