@@ -682,3 +682,42 @@ def test_beam_topk_and_cache_reorder_at_full_width(big64, B, K, M):
     _cabi.check(lib.opus_kv_reorder(model._ctx, perm.int().contiguous().data_ptr(), R, None))
     got = model.decode_logits(tok[perm])
     assert rel_l2(got, ref[perm]) < 1e-5                       # (same kernels, same rows' values: equal up to the row's position in the launch)
+
+
+@pytest.mark.parametrize("B,K,M", [(8, 4, 8), (3, 2, 6)])
+def test_beam_sample_step_at_full_width(big64, B, K, M):
+    """Beam-sample's device step at the Llama-3-8B vocabulary (128 256) on this context's own logits: (a) every drawn continuation
+    lies in the kept set of its beam row (oracle: log_softmax, temperature, TopK(50) - the pinned transformers' default -, nucleus)
+    and carries that row's accumulated log-probability at ITS flat index k V + token (a wrong index would carry another value);
+    the M draws of a batch row are distinct; (b) the same (seed, step) draws the same continuations, another step others."""
+    import oracle
+    from opus_pllm_amd import _cabi
+    cfg, model = big64
+    dev = model.device
+    lib = _cabi.lib()
+    R, T, V = B * K, 16, cfg.dec_vocab
+    g = torch.Generator().manual_seed(B * 10 + K)
+    emb = (torch.randn(R, T, cfg.dec_dim, generator=g) * 0.5).half().to(dev)
+    mask = torch.ones(R, T, dtype=torch.uint8, device=dev)
+    lg = model.prefill_logits(emb, mask).float().cpu()
+    run = torch.randn(B, K, generator=g) * 0.5
+    d_run = run.reshape(-1).to(dev)
+    sc = torch.empty(B, M, device=dev)
+    ix = torch.empty(B, M, dtype=torch.int32, device=dev)
+    model._set_top_k(50)
+    t, p = 1.3, 0.95
+    for step in range(4):
+        _cabi.check(lib.opus_beam_sample_topk(model._ctx, None, d_run.data_ptr(), B, K, M, t, p, 11, step, sc.data_ptr(), ix.data_ptr(), None))
+        s, i = sc.cpu(), ix.cpu().long()
+        for b in range(B):
+            ref = oracle.beam_sample_distribution(lg[b * K:(b + 1) * K], run[b], t, p, 50)
+            assert bool((ref[i[b]] > 0).all()), (b, step)
+            assert len(set(i[b].tolist())) == M
+            d = s[b] - torch.log(ref[i[b]])
+            assert float((d - d[0]).abs().max()) < 2e-3                  # the same normaliser in every entry
+    a = (sc.cpu().clone(), ix.cpu().clone())
+    _cabi.check(lib.opus_beam_sample_topk(model._ctx, None, d_run.data_ptr(), B, K, M, t, p, 11, 3, sc.data_ptr(), ix.data_ptr(), None))
+    assert torch.equal(ix.cpu(), a[1]) and torch.equal(sc.cpu(), a[0])
+    _cabi.check(lib.opus_beam_sample_topk(model._ctx, None, d_run.data_ptr(), B, K, M, t, p, 11, 4, sc.data_ptr(), ix.data_ptr(), None))
+    assert not torch.equal(ix.cpu(), a[1])
+    model._set_top_k(0)
