@@ -2209,6 +2209,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmParams p, int ksplit
 //  tools/stream_sweep.hip streams 235 MB at 7.5 TB/s.  Parity-green, 114 VGPRs, no scratch - and SLOWER: gate / up 49.7 vs 42.9 us,
 //  lm_head 226 vs 189 us in isolation (tools/bench_gemm.py wide16 of that commit), the decode phase +6.5 ms.  The queue depth of a
 //  pure stream is not what limits this kernel.)
+// (measured and not kept, late round 4: 7 panels per workgroup - the eighth wave only stages activations - so that gate / up's 1792
+//  panels make 256 workgroups instead of 224 (what an [8 gate | 8 up] panel layout would allow with the pair product done across
+//  lanes): 41.8 vs 42.4 us on the 28672-column shape (-1.4 %; lm_head 207 vs 197 us), timing only.  0.6 us per layer is not
+//  worth a second copy of every gate / up weight: the 224-workgroup grid costs less than the sweep's 256-vs-224 pure-stream gap.)
 template <int MT, int EPI>
 static hipError_t launch_wide(const GemmParams &p, hipStream_t s) {
     const int blocks = cdiv((p.N + 15) >> 4, 8), chunks = p.K / 64;
