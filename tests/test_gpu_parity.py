@@ -505,6 +505,45 @@ def test_generate_micro_golden_ids(micro, gold, gold_dir):
     assert torch.equal(out3, out)
 
 
+def test_random_batches_match_oracle(micro):
+    """The whole path on 16 randomly drawn batches - 1..8 rows, proteins of 1..64 residues (the shortest and the longest the
+    micro context takes included), prompts of 2..30 text ids with the <seq> token anywhere, ragged prompts left-padded as the
+    reference's driver pads them (run_opus_ddp.py:113-117) - against the oracle: spliced embeddings and mask, prefill logits, and
+    the greedy ids up to each row's first low-margin step.  (The fixtures pin a few hand-made batches; this sweeps the layouts -
+    token-packed encoder offsets, splice positions, per-row padding - that a fixed fixture cannot.)"""
+    import random
+    import oracle
+    cfg, model, W = micro
+    pipe = oracle.OraclePipeline(cfg, W)
+    rng = random.Random(20260)
+    pad, N = 0, 6
+    checked = total = 0
+    for case in range(16):
+        B = rng.randint(1, cfg.max_batch)
+        lens = [rng.choice([1, 2, 64, rng.randint(3, 63)]) for _ in range(B)]
+        seqs = [synth.synth_protein(n, 100 * case + i) for i, n in enumerate(lens)]
+        rows = []
+        for i in range(B):
+            n_text = rng.randint(2, 30)
+            ids = [rng.randint(1, cfg.dec_vocab - 1) for _ in range(n_text)]
+            ids[rng.randrange(n_text)] = -200                              # DEFAULT_SEQ_TOKEN_INDEX
+            rows.append(torch.tensor(ids, dtype=torch.long))
+        ids = opa.left_pad_sequence(rows, pad, batch_first=True)
+        mask = ids != pad
+        emb_o, mask_o, _, _ = pipe.prepare(ids, mask, seqs, True)
+        res = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, None, seqs, None, inference_mode=True)
+        emb_g, mask_g = res[4], res[2]
+        assert np.array_equal(mask_g.cpu().numpy().astype(bool), mask_o.numpy().astype(bool)), case
+        assert float((emb_g.float().cpu() - emb_o).abs().max()) < 4e-3 * max(1.0, float(emb_o.abs().max())), case
+        ref, margins, logits = pipe.generate(ids, seqs, mask, N, (), pad)
+        lg = model.prefill_logits(emb_g, mask_g.to(torch.uint8)).cpu()
+        assert rel_l2(lg, logits[0]) < REL_L2, (case, rel_l2(lg, logits[0]))
+        out = model.generate(ids, seqs, attention_mask=mask, pad_token_id=pad, do_sample=False, max_new_tokens=N)
+        checked += _check_ids(out, ref, margins) * ref.numel()
+        total += ref.numel()
+    assert checked / total > 0.6, checked / total                          # (most steps of random micro models are decisive)
+
+
 def test_generate_beam_golden(dev, gold, gold_dir):
     """Row N1, `num_beams` (eval/run_opus_ddp.py:129,158): generate(num_beams=3) against the reference's own beam search on
     the inputs of generate_micro - the best hypothesis of every row and its score, decoding to max_new_tokens and with an EOS
