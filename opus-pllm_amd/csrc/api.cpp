@@ -1439,6 +1439,7 @@ extern "C" int opus_beam_sample_topk(opus_ctx *c, const float *d_logits, const f
 // reference's pin - defaults GenerationConfig.top_k to 50 whenever it samples; the Python mirror sets that default.
 extern "C" int opus_set_sampling_top_k(opus_ctx *c, int32_t k) {
     if (!c || k < 0) return fail(OPUS_EBADARG, "set_sampling_top_k: k >= 0");
+    if (k != c->samp_top_k && c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // the captured step holds k
     c->samp_top_k = k;
     return OPUS_OK;
 }

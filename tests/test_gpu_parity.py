@@ -738,6 +738,14 @@ def test_generate_with_sampling(micro, gold, gold_dir):
     # temperature -> 0 collapses the nucleus onto the arg-max: sampling reproduces the greedy ids
     cold = model.generate(ids, seqs, do_sample=True, temperature=1e-3, top_p=0.7, seed=3, **kw)
     assert np.array_equal(cold.cpu().numpy(), g["free_ids"][:, :10])
+    # top_k changes what a replayed decode graph must do: k = 1 is the arg-max whatever the temperature (the captured step of the
+    # calls above held k = 50, the default)
+    one = model.generate(ids, seqs, do_sample=True, temperature=1.5, top_p=1.0, top_k=1, seed=7, **kw)
+    assert np.array_equal(one.cpu().numpy(), g["free_ids"][:, :10])
+    wide = model.generate(ids, seqs, do_sample=True, temperature=1.5, top_p=1.0, top_k=0, seed=7, **kw)
+    wide2 = model.generate(ids, seqs, do_sample=True, temperature=1.5, top_p=1.0, top_k=0, seed=7, **kw)
+    one2 = model.generate(ids, seqs, do_sample=True, temperature=1.5, top_p=1.0, top_k=1, seed=7, **kw)
+    assert not torch.equal(wide, one) and torch.equal(wide, wide2) and torch.equal(one2, one)
     torch.manual_seed(11)
     d = model.generate(ids, seqs, do_sample=True, temperature=0.7, top_p=0.7, **kw)             # seed from torch's RNG
     torch.manual_seed(11)
