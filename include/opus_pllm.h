@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 8
+#define OPUS_ABI_VERSION 9
 
 enum opus_status {
     OPUS_OK = 0,
@@ -223,6 +223,16 @@ int opus_debug_gemm_rope(opus_ctx *ctx, const void *d_A, const void *d_W, const 
 int opus_debug_attention(opus_ctx *ctx, const void *d_Q, const void *d_K, const void *d_V, void *d_O,
                          const int32_t *d_kstart, const int32_t *d_kend, int32_t B, int32_t T, int32_t heads,
                          int32_t group, int32_t head_dim, int32_t causal, float scale, void *stream);
+
+/* attn_decode_kernel as opus_llama_decode_step launches it, alone, on layer 0 of this context's KV cache (kernel-level parity
+ * of rows D3 / D4 at any cache length: transformers' eager attention over a cache, modeling_llama.py:191-213, reached from
+ * language_model/opus_llama.py:127).  d_qkv fp16 [B, (heads + 2 kv) hd]: the new token's q | k | v projections, not yet rotated;
+ * d_k_hist / d_v_hist fp16 [B, kv, L, hd], L = T0 + step: the cache contents of slots 0 .. L-1 (keys rotated); d_kstart int32
+ * [B]: first visible slot of each (left-padded) row.  The new token sits at slot L, position L - kstart[b].
+ * d_out fp16 [B, heads hd]; d_k_new / d_v_new (optional) fp16 [B, kv, hd]: slot L of the cache afterwards.
+ * Overwrites the cache of the last prefill (opus_llama_decode_step then fails with OPUS_ESTATE until the next prefill). */
+int opus_debug_attn_decode(opus_ctx *ctx, const void *d_qkv, const void *d_k_hist, const void *d_v_hist, const int32_t *d_kstart,
+                           int32_t B, int32_t T0, int32_t step, void *d_out, void *d_k_new, void *d_v_new, void *stream);
 
 /* Synchronises `stream` and returns OPUS_EHIP if an in-launch split-K hand-off of this context gave up waiting since the last
  * check (see Conventions; the results of the calls in between are invalid), OPUS_OK otherwise.  opus_generate_* make the same

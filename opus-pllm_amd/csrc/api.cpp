@@ -1497,6 +1497,47 @@ extern "C" int opus_debug_attention(opus_ctx *c, const void *Q, const void *K, c
     return OPUS_OK;
 }
 
+// attn_decode_kernel exactly as decode_step() launches it (finished fp16 projections in, no k-part slabs), on layer 0 of this
+// context's KV cache: the history d_k_hist / d_v_hist fp16 [B, kv heads, L, hd] (keys already rotated, as the cache holds them)
+// is copied into slots 0 .. L-1 (L = T0 + step), the step word, kstart[] and the rotary rows of the step are set as the
+// embedding kernel sets them, then ONE launch: rotary(q, k) at position L - kstart[b], append at slot L, softmax over the
+// slots kstart[b] .. L.  d_out fp16 [B, heads hd]; d_k_new / d_v_new (optional) fp16 [B, kv heads, hd] = what slot L holds
+// afterwards.  The kernel-level parity test of the key-tile loop (tests/test_gpu_longctx.py): rows D3 / D4.
+extern "C" int opus_debug_attn_decode(opus_ctx *c, const void *d_qkv, const void *d_k_hist, const void *d_v_hist,
+                                      const int32_t *d_kstart, int32_t B, int32_t T0, int32_t step, void *d_out, void *d_k_new,
+                                      void *d_v_new, void *stream) {
+    if (!c || !d_qkv || !d_kstart || !d_out) return fail(OPUS_EBADARG, "debug_attn_decode: null pointer");
+    const opus_config &g = c->cfg;
+    const int L = T0 + step, nkv = g.dec_kv_heads, hd = g.dec_head_dim;
+    if (B < 1 || B > g.max_batch || T0 < 1 || T0 > g.max_prompt || step < 0 || step >= g.max_new_tokens)
+        return fail(OPUS_ESHAPE, "debug_attn_decode: B=%d T0=%d step=%d exceed the context (%d, %d, %d)", B, T0, step, g.max_batch,
+                    g.max_prompt, g.max_new_tokens);
+    if (L > 0 && (!d_k_hist || !d_v_hist)) return fail(OPUS_EBADARG, "debug_attn_decode: history is null");
+    HIPC(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t pitch = (size_t)c->cache_sh * sizeof(half_t), roww = (size_t)L * hd * sizeof(half_t);
+    HIPC(hipMemcpy2DAsync(c->kc, pitch, d_k_hist, roww, roww, (size_t)B * nkv, hipMemcpyDeviceToDevice, s));
+    HIPC(hipMemcpy2DAsync(c->vc, pitch, d_v_hist, roww, roww, (size_t)B * nkv, hipMemcpyDeviceToDevice, s));
+    HIPC(hipMemcpyAsync(c->d_kstart, d_kstart, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIPC(launch_upload_i32(&step, 1, c->d_step, s));
+    // (the embedding kernel with a zero-width row: only its rotary-row part runs)
+    HIPC(launch_embed_tokens(c->d_next, nullptr, B, 0, 1, c->d_xl, nullptr, nullptr, 0, c->cs_dec, c->d_kstart, c->d_step, T0, hd / 2,
+                             c->cs_row, nullptr, 0, s));
+    AttnDecodeParams a;
+    a.qkv = (const half_t *)d_qkv; a.slabs = nullptr; a.ks = 0; a.slab_stride = 0; a.row_ssq = nullptr; a.row_nblk = 0; a.eps = 0.f; a.K = 0;
+    a.bias = nullptr;
+    a.cs_row = c->cs_row; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = T0; a.nh = g.dec_heads; a.nkv = nkv;
+    a.kc = c->kc; a.vc = c->vc; a.cache_sb = c->cache_sb; a.cache_sh = c->cache_sh;
+    a.ctx_cap = g.max_prompt + g.max_new_tokens; a.scale = 1.0f / sqrtf((float)hd); a.out = (half_t *)d_out; a.out_tiled = 0;
+    c->phase = PH_DECODE;
+    KL(KC_ATTN_DECODE, 4.0 * B * nkv * hd * (L + 1), launch_attn_decode(a, B, hd, s));
+    const size_t one = (size_t)hd * sizeof(half_t);
+    if (d_k_new) HIPC(hipMemcpy2DAsync(d_k_new, one, c->kc + (size_t)L * hd, pitch, one, (size_t)B * nkv, hipMemcpyDeviceToDevice, s));
+    if (d_v_new) HIPC(hipMemcpy2DAsync(d_v_new, one, c->vc + (size_t)L * hd, pitch, one, (size_t)B * nkv, hipMemcpyDeviceToDevice, s));
+    c->prefilled = false;                                     // (the cache no longer belongs to a prefill)
+    return OPUS_OK;
+}
+
 // Run-time tuning knobs (A/B aids of the benchmarks and tests; process-wide): "no_stream", "pp_gm", "misc0" .. "misc7".
 extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
     if (!name) return fail(OPUS_EBADARG, "debug_knob: null name");

@@ -168,6 +168,9 @@ def test_gemm_fused_rmsnorm(micro, dev, M, N, K, epi):
 @pytest.mark.parametrize("B,T,heads,group,hd,causal", [
     (2, 37, 4, 1, 16, 0), (1, 130, 20, 1, 16, 0), (2, 200, 3, 1, 64, 0), (3, 70, 4, 2, 32, 1),
     (2, 96, 8, 4, 128, 1), (1, 514, 2, 1, 64, 0), (2, 129, 4, 1, 128, 1),
+    # the decoder's prefill kernel (causal, head_dim 128) past 256 positions - the prompts behind a 128 / 256-token budget and the
+    # longer-prompt references of tests/test_gpu_longctx.py: 9 - 17 key tiles per query block, GQA and MHA, left padding up to T / 2
+    (3, 257, 8, 4, 128, 1), (2, 300, 4, 1, 128, 1), (3, 513, 4, 2, 128, 1), (2, 352, 6, 2, 64, 1),
 ])
 def test_attention_kernel(micro, dev, B, T, heads, group, hd, causal):
     """Flash attention vs explicit softmax: key padding (encoder), left padding + causal + GQA (decoder)."""
@@ -179,7 +182,7 @@ def test_attention_kernel(micro, dev, B, T, heads, group, hd, causal):
     k = torch.randn(B, T, kvh, hd, generator=g).half()
     v = torch.randn(B, T, kvh, hd, generator=g).half()
     if causal:
-        kstart = torch.tensor([(7 * b) % max(1, T // 2) for b in range(B)], dtype=torch.int32)
+        kstart = torch.tensor([(7 * b + (T // 3) * (b // 2) * (T > 256)) % max(1, T // 2) for b in range(B)], dtype=torch.int32)
         kend = torch.full((B,), T, dtype=torch.int32)
     else:
         kstart = torch.zeros(B, dtype=torch.int32)

@@ -26,7 +26,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _cabi.lib()                          # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 8 and lib.opus_operand_dtype() == 0
+    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 9 and lib.opus_operand_dtype() == 0
     # pure host entry points that need no GPU
     cc = _cabi.CConfig.from_config(opa.llama3_8b())
     assert lib.opus_workspace_bytes(ctypes.byref(cc)) > 1 << 30

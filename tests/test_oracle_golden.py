@@ -120,6 +120,25 @@ def test_generate_micro_golden(gold, gold_dir, micro):
     assert float(margins.min()) > 1e-3                                # the fixture is far from ties
 
 
+def test_generate_micro_long_golden(gold, gold_dir):
+    """272 greedy steps of the reference's generate() (cache grows from 79 to 351 slots, rows left-padded by 0 / 67 / 34): the
+    oracle's cached greedy loop reproduces every id and the logits that decided ids 0 / 1 / 130 / 271."""
+    g = gold("generate_micro_long")
+    seqs = json.load(open(os.path.join(gold_dir, "generate_micro_long.seqs.json")))
+    cfg = opa.micro(max_prompt=80, max_new_tokens=288)
+    W = {k: torch.from_numpy(v) for k, v in synth.canonical_weights(cfg, int(g["weights_seed"])).items()}
+    pipe = oracle.OraclePipeline(cfg, W)
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    N = g["free_ids"].shape[1]
+    assert N == 272 and int(g["T"]) + N - 1 > 3 * 128 - 64
+    out, margins, logits = pipe.generate(ids, seqs, mask, N, (), int(g["pad"]))
+    assert np.array_equal(out.numpy(), g["free_ids"])                 # token ids: bit-exact
+    for i, s_ in enumerate(g["steps"]):
+        np.testing.assert_allclose(logits[int(s_)].numpy(), g["step_logits"][:, i], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(margins.numpy(), g["margins"], atol=2e-4)
+    assert float(g["margins"].min()) == pytest.approx(float(g["min_margin"])) and float(g["min_margin"]) > 0.02
+
+
 def test_generate_beam_golden(gold, gold_dir, micro):
     """Row N1 (`num_beams`): the oracle's beam search against the reference's generate(num_beams=3, num_return_sequences=3) on
     the inputs of generate_micro - all three hypotheses of every row and their scores, decoding to max_new_tokens and with an

@@ -505,6 +505,71 @@ def _decoder_family_run(cfg, w):
     return dict(free_ids=free.numpy(), step_logits=logits[:, T - 1:T + 4].numpy()), float((top2[..., 0] - top2[..., 1]).min())
 
 
+LONG_N = 272            # new tokens of generate_micro_long: the reference's largest budget is 256 (eval/run_opus_ddp.py:93-101)
+LONG_STEPS = (0, 1, 130, 271)
+
+
+def _long_inputs(cfg):
+    rng = np.random.default_rng(17)
+    V = cfg.dec_vocab
+    r = lambda n: [int(x) for x in rng.integers(3, V, n)]          # noqa: E731
+    # spliced lengths 79 / 12 / 45: left padding of 0 / 67 / 34 slots (more than two / one 32-slot key tile of the decode attention)
+    rows = [[1] + r(40) + [-200] + r(30), [1, -200] + r(3), [1] + r(25) + [-200] + r(11)]
+    pad = 2
+    width = max(len(x) for x in rows)
+    ids = torch.full((len(rows), width), pad, dtype=torch.long)
+    for i, x in enumerate(rows):
+        ids[i, width - len(x):] = torch.tensor(x)
+    seqs = [synth.synth_protein(n, 50 + i) for i, n in enumerate((31, 12, 57))]
+    return ids, ids != pad, pad, seqs
+
+
+def _long_run(cfg, w):
+    ids, mask, pad, seqs = _long_inputs(cfg)
+    hf = build_hf_esm(cfg, w)
+    model = build_ref_model(cfg, w, FakeEncoder(hf))
+    N = LONG_N
+    with torch.no_grad():
+        free = model.generate(ids, seqs, attention_mask=mask, pad_token_id=pad, do_sample=False, max_new_tokens=N,
+                              use_cache=True, eos_token_id=None)
+        assert free.shape == (ids.shape[0], N), free.shape
+        _, _, amask, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, None, seqs, inference_mode=True)
+        # the logits that decided every id, teacher-forced on the run's own ids in ONE forward (no cache)
+        allin = torch.cat([emb, model.get_model().embed_tokens(free[:, :-1])], dim=1)
+        allm = torch.cat([amask, torch.ones(ids.shape[0], N - 1, dtype=amask.dtype)], dim=1)
+        posid = (allm.long().cumsum(-1) - 1).clamp(min=0)
+        dec = LlamaForCausalLM.forward(model, inputs_embeds=allin, attention_mask=allm.long(), position_ids=posid
+                                       ).logits[:, emb.shape[1] - 1:]
+    top2 = dec.topk(2, dim=-1).values
+    margins = (top2[..., 0] - top2[..., 1])
+    same = bool(torch.equal(dec.argmax(-1), free))     # (cached fp32 decode vs one uncached forward: equal unless a near-tie)
+    arrs = dict(ids=ids.numpy(), mask=mask.numpy(), pad=np.array(pad), free_ids=free.numpy(), margins=margins.numpy().astype(np.float32),
+                steps=np.array(LONG_STEPS), step_logits=dec[:, list(LONG_STEPS)].numpy(), T=np.array(emb.shape[1]))
+    return arrs, (float(margins.min()) if same else -1.0), seqs
+
+
+def gold_generate_long():
+    """Rows D3 / D4 / G1 past 128 cache positions (eval/run_opus_ddp.py:93-101: budgets of 128 and 256 new tokens): the
+    reference's own generate() on the micro model for 272 greedy steps from prompts of 79 / 12 / 45 positions - the cache grows
+    to 351 slots, i.e. up to three 32-slot key tiles per wave in the decode attention, rows left-padded by 67 and 34 slots.
+    Weights seed chosen by margin like the decoder-family fixtures: the first seed whose 816 ids all keep a top-1 margin >= 0.05,
+    else the best of 300 (the micro model's logits are nearly flat: over 816 ids no seed of the first 400 reaches 0.05; the best,
+    seed 259, keeps 0.0247, about 25 x the fp16 path's logits error on this model - the GPU test demands bit-exact ids above 0.02)."""
+    cfg = opa.micro(max_prompt=80, max_new_tokens=288)
+    best = None
+    for seed in range(300):
+        arrs, mm, seqs = _long_run(cfg, synth.canonical_weights(cfg, seed=seed))
+        if best is None or mm > best[2]:
+            best = (seed, arrs, mm, seqs)
+        if mm >= 0.05:
+            break
+    seed, arrs, mm, seqs = best
+    print(f"  generate_micro_long: weights seed {seed}, smallest top-1 margin over {arrs['free_ids'].size} greedy ids {mm:.4f}")
+    save("generate_micro_long", weights_seed=np.array(seed), min_margin=np.array(mm, dtype=np.float32), **arrs)
+    with open(os.path.join(GOLD, "generate_micro_long.seqs.json"), "w") as f:
+        json.dump(seqs, f)
+
+
 def gold_conversation():
     """Prompt renderings of the reference's conversation module (row N2): every separator style it renders, the
     presets, and the ChatML fallback template through a transformers tokenizer's apply_chat_template."""
@@ -561,6 +626,7 @@ def main():
     for tag, fam in (("generate_micro_opt", opa.micro_opt()), ("generate_micro_opt_relu", opa.micro_opt_relu()),
                      ("generate_micro_qwen", opa.micro_qwen())):
         print(tag); gold_decoder_family(tag, fam)
+    print("long decode (micro, 272 new tokens)"); gold_generate_long()
     print("C1 chain")
     c1 = opa.c1_tiny()
     gold_c1(c1, synth.canonical_weights(c1, seed=0))
