@@ -77,6 +77,7 @@ def parse(argv=None):
     p.add_argument("--no-c2", action="store_true", help="skip the batch-1 latency configuration (configs[1])")
     p.add_argument("--no-inflight", action="store_true", help="skip the two-batches-in-flight measurement (`two_in_flight`)")
     p.add_argument("--no-e2e", action="store_true", help="skip the strings-in -> ids-out measurement through model.generate (`e2e`)")
+    p.add_argument("--no-var-t", action="store_true", help="skip the dataset-shaped run with per-batch prompt lengths (`e2e_var_T`)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     return p.parse_args(argv)
@@ -98,6 +99,9 @@ def self_launch(a) -> int:
     return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
 
 
+FORCE_COLLECTIVE = False       # set in main() from OPUS_BENCH_FORCE_COLLECTIVE=1
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 class Workload:
     """One batch of synthetic input resident in HBM + the step that runs the path over it."""
@@ -108,7 +112,7 @@ class Workload:
         from opus_pllm_amd.alphabet import batch_convert
         self.model, self.B, self.N_new, self.lengths = model, B, a.new_tokens, lengths
         self.sampler = (a.temperature, a.top_p, 1234) if a.temperature > 0 else None
-        # the workload the committed PMC passes were taken on (profiles/r04_pmc_traffic_b{64,1}.json): see roofline()
+        # the workload the committed PMC passes are taken on (profiles/r<NN>_pmc_traffic_b{64,1}.json): see roofline()
         self.pmc_workload = (a.model == "llama3_8b" and a.new_tokens == 32 and self.sampler is None and not a.padded_encoder
                              and B in (1, 64) and all(n == 512 for n in lengths))
         seqs = [synth.synth_protein(n, rank * B + i) for i, n in enumerate(lengths)]
@@ -174,18 +178,19 @@ class DryWorkload:
 def timed(work, a, world, rank, dev, dist, cdev, steps, warmup):
     """W untimed + exactly K timed steps between barrier + synchronize fences; max over ranks.  -> (seconds, last ids)"""
     import torch
-    gathered = [torch.empty((work.B, work.N_new), dtype=torch.long, device=cdev) for _ in range(world)] if world > 1 else None
+    coll = world > 1 or FORCE_COLLECTIVE      # (OPUS_BENCH_FORCE_COLLECTIVE=1: the N > 1 code path on one rank, tests/test_gpu_rccl.py)
+    gathered = [torch.empty((work.B, work.N_new), dtype=torch.long, device=cdev) for _ in range(world)] if coll else None
 
     def step():
         out = work.run()
-        if world > 1:
+        if coll:
             dist.all_gather(gathered, out.contiguous().to(cdev))   # RCCL over xGMI: [B, N_new] ids per rank
         return out
 
     def fence():
         if dev is not None:
             torch.cuda.synchronize(dev)
-        if world > 1:
+        if coll:
             dist.barrier()
         if dev is not None:
             torch.cuda.synchronize(dev)
@@ -201,7 +206,7 @@ def timed(work, a, world, rank, dev, dist, cdev, steps, warmup):
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -250,6 +255,77 @@ def two_in_flight(model, cfg, a, rank, lengths, dev, steps, warmup):
                     "kernel times of the two streams overlap (their sum exceeds the wall time)"}
 
 
+def e2e_var_T(model, cfg, a, rank, lengths, dev, n_batches=20):
+    """A dataset-shaped run through the product entry point (model.generate on host ids + strings, as eval/run_opus_ddp.py:88-135
+    drives it): `n_batches` batches whose prompts differ in length from batch to batch (spliced T drawn from 60-200, rows of a
+    batch ragged by up to 20 positions, i.e. left-padded) and a SHORT last batch.  Three timings of the same proteins:
+    `var_T` (one decode hipGraph per batch size, shared by every prompt length: the step reads T0 from device memory),
+    `fixed_T` (every prompt at the mean length: what the fixed-shape bench lines measure) and `var_T_recapture` (the graphs are
+    dropped before every batch: round 4's behaviour, a capture + instantiation per batch).  Second context on the same weights
+    (its workspace holds 208 prompt positions; the headline's context keeps its 96)."""
+    import numpy as np
+    import torch
+    from opus_pllm_amd import synth
+    from opus_pllm_amd.model import OpusLlamaForCausalLM
+    B, N_new = a.batch, a.new_tokens
+    cfg2 = cfg.with_capacity(max_prompt=208)
+    m2 = OpusLlamaForCausalLM(cfg2, model.weights, dev)
+    m2.packed_encoder = model.packed_encoder
+    rng = np.random.default_rng(2024)
+    Ts = [int(t) for t in rng.integers(60, 201, n_batches)]
+    sizes = [B] * (n_batches - 1) + [max(1, B // 2 + 3)]
+    seqs = [[synth.synth_protein(lengths[i % len(lengths)], 7000 + 97 * k + i) for i in range(sizes[k])] for k in range(n_batches)]
+
+    def prompts(k, T, ragged):
+        rows = []
+        for i in range(sizes[k]):
+            n_text = T - 7 - (int(rng.integers(0, 21)) if ragged and i else 0)       # spliced length = n_text - 1 + 8; row 0 is the longest
+            rows.append(synth.synth_prompt_ids(cfg.dec_vocab, 1000 * k + i, n_text=n_text, seq_pos=min(41, n_text - 2)))
+        width = max(len(r) for r in rows)
+        ids = torch.zeros((len(rows), width), dtype=torch.long)
+        mask = torch.zeros((len(rows), width), dtype=torch.bool)
+        for i, r in enumerate(rows):
+            ids[i, width - len(r):] = torch.tensor(r)
+            mask[i, width - len(r):] = True
+        return ids, mask
+
+    var = [prompts(k, Ts[k], True) for k in range(n_batches)]
+    Tm = int(round(sum(Ts) / len(Ts)))
+    fix = [prompts(k, Tm, False) for k in range(n_batches)]
+
+    def one_pass(batches, drop=False):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        outs = []
+        for k, (ids, mask) in enumerate(batches):
+            if drop:
+                m2.drop_decode_graphs()
+            outs.append(m2.generate(ids, seq=seqs[k], attention_mask=mask, max_new_tokens=N_new, do_sample=False, eos_token_id=[], pad_token_id=0))
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, outs
+
+    n0 = m2.stat("graph_instantiations")
+    _, first = one_pass(var)                                   # first pass: graphs are captured here
+    n1 = m2.stat("graph_instantiations")
+    dt_var, again = one_pass(var)
+    n2 = m2.stat("graph_instantiations")
+    one_pass(fix)
+    dt_fix, _ = one_pass(fix)
+    dt_rec, rec = one_pass(var, drop=True)
+    n3 = m2.stat("graph_instantiations")
+    same = all(bool(torch.equal(x, y)) and bool(torch.equal(x, z)) for x, y, z in zip(first, again, rec))
+    prot = sum(sizes)
+    del m2
+    torch.cuda.empty_cache()
+    return {"batches": n_batches, "batch_sizes": f"{n_batches - 1} x {B} + 1 x {sizes[-1]}", "spliced_T": Ts, "fixed_T": Tm, "new_tokens": N_new,
+            "var_T": {"proteins_per_sec": prot / dt_var, "ms_per_batch": 1e3 * dt_var / n_batches, "graph_instantiations": n2 - n1},
+            "fixed_T": {"proteins_per_sec": prot / dt_fix, "ms_per_batch": 1e3 * dt_fix / n_batches},
+            "var_T_recapture": {"proteins_per_sec": prot / dt_rec, "ms_per_batch": 1e3 * dt_rec / n_batches, "graph_instantiations": n3 - n2},
+            "var_T_over_fixed_T": dt_fix / dt_var, "graph_instantiations_first_pass": n1 - n0, "ids_identical_across_passes": same,
+            "note": "model.generate(host ids, list[str]) per batch; the captured decode step reads the prompt length from device memory, so "
+                    "only a new batch SIZE instantiates a graph (first pass: the full batches' and the short last batch's)"}
+
+
 def rank_diagnostics(work, world, rank, dev, dist, cdev, steps=3):
     """N > 1 only, untimed, after the timed region: what the one max-over-ranks number cannot say.  Every rank times `steps`
     more steps with a device synchronize after the path and another after the id gather, so that a slow RANK (its own path
@@ -287,6 +363,27 @@ def rank_diagnostics(work, world, rank, dev, dist, cdev, steps=3):
 
 
 # ------------------------------------------------------------------------------------------------ roofline
+def sources_sha16():
+    """Hash of the kernel sources that are running (opus-pllm_amd/build.py sources_sha16)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_opus_build", os.path.join(os.path.dirname(os.path.abspath(__file__)), "opus-pllm_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.sources_sha16()
+
+
+def newest_pmc_summary(B):
+    """profiles/r<NN>_pmc_traffic_b<B>.json of the highest round, or None."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r*_pmc_traffic_b{B}.json")):
+        m = re.match(r"r(\d+)_pmc_traffic_b\d+\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 HBM_CLASSES = ("gemm_skinny", "gemm_mid", "gemm_wide", "gemm_stream", "attn_decode", "splitk_reduce", "norm", "other")
 
 
@@ -331,20 +428,30 @@ def roofline(model, work, dev):
     # traffic: counters cannot be collected inside bench.py (rocprofv3 --pmc passes of THIS command, one counter set per pass:
     # tools/prof_step.sh, summarised by tools/pmc_summary.py) - the committed summary of the last such passes is reported here,
     # per launch of the dominant class, when it was taken on the workload this run measures
-    traffic, traffic_note = None, "no committed PMC summary for this workload (tools/prof_step.sh + tools/pmc_summary.py)"
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r04_pmc_traffic_b{work.B}.json")
-    if os.path.exists(pmc_file) and getattr(work, "pmc_workload", False):
+    traffic, traffic_note, committed = None, "no committed PMC summary for this workload (tools/prof_step.sh + tools/pmc_summary.py)", None
+    pmc_file, cur_sha = newest_pmc_summary(work.B), sources_sha16()
+    if pmc_file and getattr(work, "pmc_workload", False):
         try:
-            c = json.load(open(pmc_file))["classes"].get(dom)
+            doc = json.load(open(pmc_file))
+            c = doc["classes"].get(dom)
             if c and c.get("launches"):
-                traffic = c["fabric_bytes"] / c["launches"]
-                traffic_note = (f"L2<->fabric bytes per launch of {dom} (TCC_EA0 read requests, gfx950-corrected, + WRITE_SIZE; Infinity-Cache "
-                                f"hits are counted) from the committed rocprofv3 --pmc passes of this command, profiles/{os.path.basename(pmc_file)}: "
-                                f"{c['ratio']:.2f} x the algorithmic bytes of that pass; collected in separate passes, not in this run")
+                per_launch = c["fabric_bytes"] / c["launches"]
+                committed = {"file": "profiles/" + os.path.basename(pmc_file), "kernel_class": dom, "bytes_per_launch": per_launch,
+                             "ratio_to_algorithmic": c["ratio"], "csrc_sha16_of_passes": doc.get("csrc_sha16"), "csrc_sha16_now": cur_sha}
+                if doc.get("csrc_sha16") == cur_sha:
+                    traffic = per_launch
+                    traffic_note = (f"L2<->fabric bytes per launch of {dom} (TCC_EA0 read requests, gfx950-corrected, + WRITE_SIZE; Infinity-Cache "
+                                    f"hits are counted) from the committed rocprofv3 --pmc passes of this command, {committed['file']}, taken on "
+                                    f"the kernel sources that are running now (csrc sha {cur_sha}): {c['ratio']:.2f} x the algorithmic bytes of "
+                                    f"that pass; collected in separate passes, not in this run")
+                else:
+                    traffic_note = (f"null: the newest committed PMC passes ({committed['file']}) were taken on other kernel sources (csrc sha "
+                                    f"{doc.get('csrc_sha16')} then, {cur_sha} now) - see committed_pmc_traffic; refresh with tools/refresh_profiles.sh")
         except (OSError, ValueError, KeyError):
             pass
     res.update({"kernel": f"{dom} (largest summed duration of the step: {100.0 * ms / all_ms:.0f} % of kernel time)",
                 "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "traffic": traffic, "traffic_note": traffic_note,
+                "committed_pmc_traffic": committed,
                 "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])},
                 "algorithmic_gb_per_step": {k: round(v[2] / 1e9, 4) for k, v in tot.items()},
                 "algorithmic_tflop_per_step": {k: round(v[3] / 1e12, 4) for k, v in tot.items() if v[3] > 0},
@@ -483,9 +590,13 @@ def main():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    global FORCE_COLLECTIVE
+    FORCE_COLLECTIVE = os.environ.get("OPUS_BENCH_FORCE_COLLECTIVE") == "1" and not dry
+    if world > 1 or FORCE_COLLECTIVE:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         tmo = datetime.timedelta(seconds=RDZV_TIMEOUT_S)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
@@ -559,6 +670,11 @@ def main():
                               "bucketing, host->device copies, encode, projectors, splice, prefill, decode, ids back as a LongTensor; "
                               "what the reference's entries/sec loop times per batch minus its text (de)tokeniser"}
 
+    if not dry and not a.no_var_t and world == 1 and B >= 8:
+        res["e2e_var_T"] = e2e_var_T(model, cfg, a, rank, main_work.lengths, dev)
+        log(f"e2e_var_T: {res['e2e_var_T']['var_T']['ms_per_batch']:.2f} ms/batch (fixed T {res['e2e_var_T']['fixed_T']['ms_per_batch']:.2f}, "
+            f"per-batch recapture {res['e2e_var_T']['var_T_recapture']['ms_per_batch']:.2f})")
+
     if not dry and not a.no_inflight and world == 1 and a.steps >= 2:
         res["two_in_flight"] = two_in_flight(model, cfg, a, rank, main_work.lengths, dev, a.steps, a.warmup)
         log(f"two batches in flight: {res['two_in_flight']['ms_per_step']:.2f} ms/step")
@@ -574,16 +690,17 @@ def main():
                 res["c2"]["roofline"] = r_c2
             if r_proj is not None:
                 res["projector_stage"] = r_proj
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVE:
         diag = rank_diagnostics(main_work, world, rank, dev, dist, cdev)
         if rank == 0:
             res["ranks"] = diag
+            res["collective_backend"] = backend
         dist.barrier()
     if rank == 0 and world == 1 and not dry and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, main_work.lengths[0], main_work.n_text, N_new, B)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVE:
         dist.barrier()
         dist.destroy_process_group()
 

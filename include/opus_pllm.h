@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OPUS_ABI_VERSION 9
+#define OPUS_ABI_VERSION 10
 
 enum opus_status {
     OPUS_OK = 0,
@@ -252,7 +252,8 @@ int opus_beam_topk(opus_ctx *ctx, const float *d_run_scores, int32_t B, int32_t 
 int opus_kv_reorder(opus_ctx *ctx, const int32_t *d_src_rows, int32_t R, void *stream);
 /* Beam-sample (`num_beams` > 1 with temperature > 0: run_opus_ddp.py:126-129 passes both; _get_top_k_continuations' do_sample
  * branch = torch.multinomial(softmax(accumulated), M), without replacement).  Per decoder row: log_softmax, then the warpers on
- * the log-probabilities (temperature, top_k of opus_set_sampling_top_k, top_p); per batch row: M continuations drawn without
+ * the log-probabilities (temperature, top_k of opus_set_sampling_top_k, top_p - both with min_tokens_to_keep = M / K, i.e. #eos + 1
+ * and at least 2, as GenerationMixin._get_logits_processor builds them when num_beams > 1); per batch row: M continuations drawn without
  * replacement from softmax over the K rows' kept values + run_scores.  d_scores fp32 [B, M] = the accumulated log-probabilities of
  * the draws, d_idx int32 [B, M] = k * dec_vocab + token, in the order drawn; entries beyond the continuations of non-zero
  * probability are -inf / 0x7fffffff (torch.multinomial raises there: the caller should).  Draws come from a counter-based generator
@@ -268,6 +269,13 @@ int opus_set_sampling_top_k(opus_ctx *ctx, int32_t k);
 /* fp32 logits [B, dec_vocab] of the most recent prefill / decode step (device copy on `stream`): the payload of the
  * optional logits all-gather of SURVEY 8e (ids are what eval/run_opus_ddp.py:138 gathers). */
 int opus_last_logits(opus_ctx *ctx, float *d_out, int32_t B, void *stream);
+
+/* Counters of a context (no reference counterpart; -1 for an unknown name).  "graph_instantiations": decode-step hipGraphs
+ * instantiated since the context was created - the captured step reads the prompt length from device memory, so a dataset's
+ * batches share one graph whatever their T (the reference's loop, eval/run_opus_ddp.py:88-135, brings a new T with every batch);
+ * a different number of rows / token budget / sampling setting is another graph (a few are kept).  "graph_replays": decode steps
+ * launched from a graph.  "graphs_cached". */
+int64_t opus_stat(opus_ctx *ctx, const char *name);
 
 /* Measurement support (bench.py).  With timing enabled (off by default; decode runs eagerly instead of from the
  * hipGraph) every kernel launch of the path is recorded with its own dispatch start / end events on the launch stream

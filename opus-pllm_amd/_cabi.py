@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # -DOPUS_BF16); default: fp16, the reference's unquantised dtype (model/builder.py:57)
 BF16 = os.environ.get("OPUS_DTYPE", "fp16").lower() in ("bf16", "bfloat16")
 LIB_PATH = os.environ.get("OPUS_LIB_PATH") or os.path.join(_HERE, "lib", "libopus_pllm_bf16.so" if BF16 else "libopus_pllm.so")   # (OPUS_LIB_PATH: A/B builds)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 OPUS_F16, OPUS_F32, OPUS_I32, OPUS_I64, OPUS_U8 = 0, 1, 2, 3, 4      # (OPUS_F16 = the build's 16-bit operand type)
 
@@ -103,6 +103,7 @@ SIGNATURES = {
     "opus_set_stop_sequence": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
     "opus_debug_gemm_slabs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P]),
     "opus_debug_knob": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "opus_stat": (C.c_int64, [_P, C.c_char_p]),
     "opus_debug_attn_decode": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "opus_debug_gemm_rowscale": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_float, C.POINTER(C.c_int32), _P]),

@@ -62,6 +62,20 @@ def check_resources(ru_file: str) -> None:
         raise RuntimeError(f"{os.path.basename(ru_file)}: hot kernels must not spill:\n  " + "\n  ".join(bad))
 
 
+def sources_sha16() -> str:
+    """First 16 hex digits of the SHA-256 over the kernel sources (csrc/*.hip, *.cpp, *.h in name order, and the C ABI header):
+    what a measurement that cannot be repeated inside bench.py (the rocprofv3 --pmc passes behind `roofline.traffic`) records, so
+    that a later run can tell whether it still describes the kernels that are running (tools/pmc_summary.py, bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith((".hip", ".cpp", ".h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "opus_pllm.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _deps_mtime() -> float:
     hdrs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "opus_pllm.h"))

@@ -97,11 +97,23 @@ struct opus_ctx {
     // decode state
     int cur_B = 0, cur_T = 0;
     bool prefilled = false;
-    // graph cache for the decode iteration
-    hipGraphExec_t gexec = nullptr;
-    int g_B = -1, g_T = -1, g_maxnew = -1, g_pad = 0, g_neos = -1;
-    const int32_t *g_out = nullptr;
-    float g_temp = 0.f, g_top_p = 1.f;
+    // Graph cache for the decode iteration.  A captured step does NOT depend on the prompt length: T0 reaches its kernels through
+    // the device word d_step[1] (d_step[0] = the step counter), so one instantiated graph serves every batch of a dataset whatever
+    // its T.  It does depend on the number of rows (grid sizes, kernel routing), the token budget (stride of the id matrix), the
+    // pad / EOS / sampling settings and the id buffer: a few entries are kept (a dataset's full batches + its short last batch),
+    // least recently used first out.
+    struct GraphEntry {
+        hipGraphExec_t exec = nullptr;
+        int B = -1, maxnew = -1, pad = 0, neos = -1;
+        const int32_t *out = nullptr;
+        float temp = 0.f, top_p = 1.f;
+        uint64_t used = 0;
+    };
+    static constexpr int MAX_GRAPHS = 4;
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    int64_t graph_instantiations = 0;    // opus_stat("graph_instantiations")
+    int64_t graph_replays = 0;
     // row-scale fusion (GemmParams::xh_out / row_ssq): one-shot request for the next gemm() and its outcome
     half_t *rq_xh = nullptr;
     int rq_done = 0;
@@ -333,11 +345,17 @@ static void timing_clear(opus_ctx *c) {
     c->recs.clear();
 }
 
+static void drop_graphs(opus_ctx *c) {   // a captured step holds weight pointers, the stop sequence, top-k, knobs ...
+    for (auto &g : c->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
 extern "C" int opus_ctx_destroy(opus_ctx *c) {
     if (!c) return OPUS_OK;
     (void)hipSetDevice(c->device);
     timing_clear(c);
-    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    drop_graphs(c);
     if (c->ws) (void)hipFree(c->ws);
     if (c->proj_big) (void)hipFree(c->proj_big);
     if (c->kv_tmp) (void)hipFree(c->kv_tmp);
@@ -359,8 +377,7 @@ extern "C" int opus_bind_weight(opus_ctx *c, const char *name, const void *d_ptr
     c->w[name] = t;
     c->resolved = false;
     // a captured decode graph holds the device pointers of the weights it was recorded with
-    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-    c->g_B = -1;
+    drop_graphs(c);
     return OPUS_OK;
 }
 
@@ -854,6 +871,14 @@ static int lm_head(opus_ctx *c, hipStream_t s, int B) {
 }
 
 
+// d_step = {step counter = 0, T0 = prompt length}: the decode step's kernels read BOTH from the device (a captured step is
+// then independent of the prompt length; through the kernel arguments, so the launch is stream-ordered and needs no host buffer)
+static int reset_step(opus_ctx *c, hipStream_t s, int T0, int step = 0) {
+    const int32_t v[2] = {step, T0};
+    HIPC(launch_upload_i32(v, 2, c->d_step, s));
+    return OPUS_OK;
+}
+
 // decode-step attention of layer l over the projection output in d_qkv (rows of the last prefill, T prompt positions)
 // (slab_ks > 0: the QKV GEMM left slab_ks raw k-part slabs in the GEMM workspace and the sums of squares of its input rows in
 // d_ssq: summed, scaled and biased by the attention kernel itself)
@@ -867,7 +892,7 @@ static int attn_decode(opus_ctx *c, hipStream_t s, int l, int B, int T, int slab
         a.qkv = nullptr; a.slabs = c->gemm_ws; a.ks = slab_ks; a.slab_stride = (int64_t)B * QKVd;
         a.row_ssq = c->d_ssq; a.row_nblk = c->ssq_nblk; a.eps = g.dec_rms_eps; a.K = g.dec_dim; a.bias = bias;
     }
-    a.cs_row = c->cs_row; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = T; a.nh = g.dec_heads; a.nkv = g.dec_kv_heads;
+    a.cs_row = c->cs_row; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = -1; a.nh = g.dec_heads; a.nkv = g.dec_kv_heads;   // (T0 < 0: d_step[1])
     a.kc = c->kc + l * c->cache_sl; a.vc = c->vc + l * c->cache_sl; a.cache_sb = c->cache_sb; a.cache_sh = c->cache_sh;
     a.ctx_cap = g.max_prompt + g.max_new_tokens; a.scale = 1.0f / sqrtf((float)g.dec_head_dim); a.out = c->d_ctx;
     a.out_tiled = out_tiled;
@@ -933,7 +958,7 @@ static int prefill_opt(opus_ctx *c, hipStream_t s, const half_t *embeds, const u
     for (int l = 0; l < g.dec_layers; ++l) OPC(opt_layer(c, s, c->dec[l], l, c->d_x, c->d_xn, M, B, T, false));
     KL(KC_OTHER, 8.0 * B * H, launch_take_last(c->d_x, B, T, H, c->d_xl, s));
     OPC(lm_head_opt(c, s, B));
-    HIPC(hipMemsetAsync(c->d_step, 0, sizeof(int32_t), s));
+    OPC(reset_step(c, s, T));
     c->cur_B = B;
     c->cur_T = T;
     c->prefilled = true;
@@ -944,7 +969,7 @@ static int prefill_opt(opus_ctx *c, hipStream_t s, const half_t *embeds, const u
 static int decode_step_opt(opus_ctx *c, hipStream_t s) {
     const opus_config &g = c->cfg;
     const int B = c->cur_B, T = c->cur_T, H = g.dec_dim;
-    KL(KC_OTHER, 10.0 * B * H, launch_add_pos(c->d_xl, c->dec_pos, c->d_kstart, c->d_step, T, B, 1, H, g.dec_max_pos + 1, s));
+    KL(KC_OTHER, 10.0 * B * H, launch_add_pos(c->d_xl, c->dec_pos, c->d_kstart, c->d_step, -1, B, 1, H, g.dec_max_pos + 1, s));   // (t0 < 0: d_step[1])
     for (int l = 0; l < g.dec_layers; ++l) OPC(opt_layer(c, s, c->dec[l], l, c->d_xl, c->d_xln, B, B, T, true));
     OPC(lm_head_opt(c, s, B));
     KL(KC_OTHER, 8.0, launch_step_advance(c->d_step, s));
@@ -1033,7 +1058,7 @@ static int prefill(opus_ctx *c, hipStream_t s, const half_t *embeds, const uint8
         c->xh_src = nullptr;
     }
     OPC(lm_head(c, s, B));
-    HIPC(hipMemsetAsync(c->d_step, 0, sizeof(int32_t), s));
+    OPC(reset_step(c, s, T));
     c->cur_B = B;
     c->cur_T = T;
     c->prefilled = true;
@@ -1059,8 +1084,8 @@ static int decode_step(opus_ctx *c, hipStream_t s, const int32_t *d_tok) {
     const bool wo_tiled = rowscale && gemm_stream_would(B, H, QD, 0, 1, 0, c->gemm_ws_bytes);
     const bool down_tiled = rowscale && (F & 63) == 0 && gemm_stream_would(B, H, F, 0, 1, 0, c->gemm_ws_bytes);
     KL(KC_OTHER, 6.0 * B * H, launch_embed_tokens(d_tok, c->dec_emb, B, H, g.dec_vocab, c->d_xl, rowscale ? c->d_xln : nullptr,
-                                                  rowscale ? c->d_ssq : nullptr, qkv_tiled ? 1 : 0, c->cs_dec, c->d_kstart, c->d_step, T,
-                                                  hd / 2, c->cs_row, c->d_cnt, HANDOFF_ERR, s));     // (+ zeroes the hand-off words)
+                                                  rowscale ? c->d_ssq : nullptr, qkv_tiled ? 1 : 0, c->cs_dec, c->d_kstart, c->d_step, -1,
+                                                  hd / 2, c->cs_row, c->d_cnt, HANDOFF_ERR, s));     // (+ zeroes the hand-off words; T0 < 0: d_step[1])
     c->xln_tiled = qkv_tiled;
     c->xh_src = rowscale ? c->d_xl : nullptr;
     if (rowscale) c->ssq_nblk = H >> 8;
@@ -1203,11 +1228,14 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
 
     // OPUS_NO_GRAPH=1: eager launches (rocprofv3 --pmc cannot collect counters through graph replays)
     const bool use_graph = s != nullptr && !c->timing && !getenv("OPUS_NO_GRAPH");
-    auto graph_matches = [&]() {
-        return c->gexec && c->g_B == B && c->g_T == T && c->g_maxnew == max_new && c->g_pad == pad_id &&
-               c->g_neos == n_eos && c->g_out == d_out_ids && c->g_temp == temperature && c->g_top_p == top_p;
+    auto find_graph = [&]() -> opus_ctx::GraphEntry * {
+        for (auto &e : c->graphs)
+            if (e.exec && e.B == B && e.maxnew == max_new && e.pad == pad_id && e.neos == n_eos && e.out == d_out_ids &&
+                e.temp == temperature && e.top_p == top_p) return &e;
+        return nullptr;
     };
-    const bool same_graph = graph_matches();
+    opus_ctx::GraphEntry *ge = use_graph ? find_graph() : nullptr;
+    const bool same_graph = ge != nullptr;
     std::vector<int32_t> nunf(max_new, 1);
     int produced = 0;
     for (int i = 0; i < max_new; ++i) {
@@ -1219,22 +1247,31 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
         if (!use_graph || (i == 0 && !same_graph)) {
             OPC(greedy_body(c, s, max_new, n_eos, pad_id, d_out_ids));   // eager (also warms lazily-set attributes)
         } else {
-            if (!graph_matches()) {
-                if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            if (!ge) {
                 hipGraph_t graph = nullptr;
                 HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 int rc = greedy_body(c, s, max_new, n_eos, pad_id, d_out_ids);
                 hipError_t ee = hipStreamEndCapture(s, &graph);
                 if (rc != OPUS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
                 if (ee != hipSuccess) return fail(OPUS_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ee));
-                ee = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+                opus_ctx::GraphEntry e;
+                ee = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
-                if (ee != hipSuccess) { c->gexec = nullptr; return fail(OPUS_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ee)); }
-                c->g_B = B; c->g_T = T; c->g_maxnew = max_new; c->g_pad = pad_id; c->g_neos = n_eos;
-                c->g_temp = temperature; c->g_top_p = top_p;
-                c->g_out = d_out_ids;
+                if (ee != hipSuccess) return fail(OPUS_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ee));
+                ++c->graph_instantiations;
+                e.B = B; e.maxnew = max_new; e.pad = pad_id; e.neos = n_eos; e.temp = temperature; e.top_p = top_p; e.out = d_out_ids;
+                if ((int)c->graphs.size() >= opus_ctx::MAX_GRAPHS) {           // least recently used out
+                    size_t v = 0;
+                    for (size_t k = 1; k < c->graphs.size(); ++k) if (c->graphs[k].used < c->graphs[v].used) v = k;
+                    (void)hipGraphExecDestroy(c->graphs[v].exec);
+                    c->graphs.erase(c->graphs.begin() + v);
+                }
+                c->graphs.push_back(e);
+                ge = &c->graphs.back();
             }
-            HIPC(hipGraphLaunch(c->gexec, s));
+            ge->used = ++c->graph_clock;
+            ++c->graph_replays;
+            HIPC(hipGraphLaunch(ge->exec, s));
         }
         produced = i + 1;
         // HF stops as soon as every row has finished; poll every 8 steps (finished rows emit pad, so
@@ -1264,8 +1301,7 @@ extern "C" int opus_set_stop_sequence(opus_ctx *c, const int32_t *ids, int32_t n
     HIPC(hipSetDevice(c->device));
     if (n) HIPC(hipMemcpy(c->d_stop, ids, n * sizeof(int32_t), hipMemcpyHostToDevice));
     c->n_stop = n;
-    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // the captured step holds n_stop
-    c->g_B = -1;
+    drop_graphs(c);                                                               // the captured step holds n_stop
     return OPUS_OK;
 }
 
@@ -1426,11 +1462,17 @@ extern "C" int opus_beam_sample_topk(opus_ctx *c, const float *d_logits, const f
     const float *lg = d_logits ? d_logits : c->d_logits;
     const int V = c->cfg.dec_vocab, R = B * K;
     c->phase = PH_DECODE;
+    // min_tokens_to_keep of both warpers under beam-sample: #eos + 1, at least 2 (generation/utils.py _get_logits_processor,
+    // "keep at least one non-eos token") = M / K, since M = max(2, 1 + #eos) K candidates are drawn per batch row
+    const int min_keep = M / K > 1 ? M / K : 1;
+    const int top_k = c->samp_top_k > 0 && c->samp_top_k < min_keep ? min_keep : c->samp_top_k;    // TopKLogitsWarper: max(top_k, min_tokens_to_keep)
     KL(KC_OTHER, 4.0 * 4 * R * V,
-       launch_sample_select(lg, R, V, temperature, top_p, c->samp_top_k, nullptr, nullptr, c->d_pval, c->d_pidx, c->d_probs, c->d_cand_i,
+       launch_sample_select(lg, R, V, temperature, top_p, top_k, nullptr, nullptr, c->d_pval, c->d_pidx, c->d_probs, c->d_cand_i,
                             c->d_cand_n, c->d_zpart, c->d_spart, nullptr, c->d_bthr, s));
+    // (the candidate lists of the nucleus search are consumed: their buffers hold the rows' min_keep best logits next)
     KL(KC_OTHER, 12.0 * R * V,
-       launch_beam_sample(lg, d_run_scores, B, K, V, M, temperature, c->d_pval, c->d_bthr, seed, step, c->d_blse, d_scores, d_idx, s));
+       launch_beam_sample(lg, d_run_scores, B, K, V, M, temperature, c->d_pval, c->d_bthr, min_keep, c->d_probs, c->d_cand_i, seed, step,
+                          c->d_blse, d_scores, d_idx, s));
     return OPUS_OK;
 }
 
@@ -1439,7 +1481,7 @@ extern "C" int opus_beam_sample_topk(opus_ctx *c, const float *d_logits, const f
 // reference's pin - defaults GenerationConfig.top_k to 50 whenever it samples; the Python mirror sets that default.
 extern "C" int opus_set_sampling_top_k(opus_ctx *c, int32_t k) {
     if (!c || k < 0) return fail(OPUS_EBADARG, "set_sampling_top_k: k >= 0");
-    if (k != c->samp_top_k && c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }   // the captured step holds k
+    if (k != c->samp_top_k) drop_graphs(c);                                      // the captured step holds k
     c->samp_top_k = k;
     return OPUS_OK;
 }
@@ -1456,12 +1498,14 @@ extern "C" int opus_kv_reorder(opus_ctx *c, const int32_t *d_src_rows, int32_t R
     const size_t row = (size_t)c->cache_sb, layer = row * g.max_batch;
     if (!c->kv_tmp) HIPC(hipMalloc((void **)&c->kv_tmp, 2 * layer * sizeof(half_t)));
     c->phase = PH_DECODE;
+    // only the filled slots (0 .. T + *step - 1, read from the device step word) of the rows that change place move
+    const int nkv = g.dec_kv_heads, hd = g.dec_head_dim, T0 = c->cur_T;
     for (int l = 0; l < g.dec_layers; ++l) {
         half_t *kc = c->kc + l * c->cache_sl, *vc = c->vc + l * c->cache_sl;
-        KL(KC_OTHER, 8.0 * R * row, launch_kv_gather_rows(kc, c->kv_tmp, d_src_rows, R, (int64_t)row, s));
-        HIPC(launch_kv_gather_rows(vc, c->kv_tmp + layer, d_src_rows, R, (int64_t)row, s));
-        HIPC(hipMemcpyAsync(kc, c->kv_tmp, (size_t)R * row * sizeof(half_t), hipMemcpyDeviceToDevice, s));
-        HIPC(hipMemcpyAsync(vc, c->kv_tmp + layer, (size_t)R * row * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+        KL(KC_OTHER, 8.0 * R * nkv * hd * T0, launch_kv_gather_rows(kc, c->kv_tmp, d_src_rows, R, (int64_t)row, nkv, c->cache_sh, c->d_step, T0, hd, 0, s));
+        HIPC(launch_kv_gather_rows(vc, c->kv_tmp + layer, d_src_rows, R, (int64_t)row, nkv, c->cache_sh, c->d_step, T0, hd, 0, s));
+        HIPC(launch_kv_gather_rows(kc, c->kv_tmp, d_src_rows, R, (int64_t)row, nkv, c->cache_sh, c->d_step, T0, hd, 1, s));
+        HIPC(launch_kv_gather_rows(vc, c->kv_tmp + layer, d_src_rows, R, (int64_t)row, nkv, c->cache_sh, c->d_step, T0, hd, 1, s));
     }
     return OPUS_OK;
 }
@@ -1519,14 +1563,14 @@ extern "C" int opus_debug_attn_decode(opus_ctx *c, const void *d_qkv, const void
     HIPC(hipMemcpy2DAsync(c->kc, pitch, d_k_hist, roww, roww, (size_t)B * nkv, hipMemcpyDeviceToDevice, s));
     HIPC(hipMemcpy2DAsync(c->vc, pitch, d_v_hist, roww, roww, (size_t)B * nkv, hipMemcpyDeviceToDevice, s));
     HIPC(hipMemcpyAsync(c->d_kstart, d_kstart, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    HIPC(launch_upload_i32(&step, 1, c->d_step, s));
+    OPC(reset_step(c, s, T0, step));
     // (the embedding kernel with a zero-width row: only its rotary-row part runs)
-    HIPC(launch_embed_tokens(c->d_next, nullptr, B, 0, 1, c->d_xl, nullptr, nullptr, 0, c->cs_dec, c->d_kstart, c->d_step, T0, hd / 2,
+    HIPC(launch_embed_tokens(c->d_next, nullptr, B, 0, 1, c->d_xl, nullptr, nullptr, 0, c->cs_dec, c->d_kstart, c->d_step, -1, hd / 2,
                              c->cs_row, nullptr, 0, s));
     AttnDecodeParams a;
     a.qkv = (const half_t *)d_qkv; a.slabs = nullptr; a.ks = 0; a.slab_stride = 0; a.row_ssq = nullptr; a.row_nblk = 0; a.eps = 0.f; a.K = 0;
     a.bias = nullptr;
-    a.cs_row = c->cs_row; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = T0; a.nh = g.dec_heads; a.nkv = nkv;
+    a.cs_row = c->cs_row; a.kstart = c->d_kstart; a.step = c->d_step; a.T0 = -1; a.nh = g.dec_heads; a.nkv = nkv;
     a.kc = c->kc; a.vc = c->vc; a.cache_sb = c->cache_sb; a.cache_sh = c->cache_sh;
     a.ctx_cap = g.max_prompt + g.max_new_tokens; a.scale = 1.0f / sqrtf((float)hd); a.out = (half_t *)d_out; a.out_tiled = 0;
     c->phase = PH_DECODE;
@@ -1541,10 +1585,7 @@ extern "C" int opus_debug_attn_decode(opus_ctx *c, const void *d_qkv, const void
 // Run-time tuning knobs (A/B aids of the benchmarks and tests; process-wide): "no_stream", "pp_gm", "misc0" .. "misc7".
 extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
     if (!name) return fail(OPUS_EBADARG, "debug_knob: null name");
-    if (c) {   // a captured decode graph replays the kernels it was recorded with
-        if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-        c->g_B = -1;
-    }
+    if (c) drop_graphs(c);   // a captured decode graph replays the kernels it was recorded with
     if (!strcmp(name, "no_stream")) g_knobs.no_stream = value;
     else if (!strcmp(name, "debug_a_tiled")) g_knobs.debug_a_tiled = value;
     else if (!strcmp(name, "no_ln_fusion")) g_knobs.no_ln_fusion = value;
@@ -1562,6 +1603,17 @@ extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
     else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '7' && !name[5]) g_knobs.misc[name[4] - '0'] = value;
     else return fail(OPUS_EBADARG, "debug_knob: unknown knob '%s'", name);
     return OPUS_OK;
+}
+
+// Counters of this context (no reference counterpart): "graph_instantiations" = decode-step hipGraphs instantiated since the
+// context was created (one per distinct batch size / token budget / sampling setting, none per prompt length);
+// "graph_replays" = decode steps launched from a graph; "graphs_cached".  Unknown name / null: -1.
+extern "C" int64_t opus_stat(opus_ctx *c, const char *name) {
+    if (!c || !name) return -1;
+    if (!strcmp(name, "graph_instantiations")) return c->graph_instantiations;
+    if (!strcmp(name, "graph_replays")) return c->graph_replays;
+    if (!strcmp(name, "graphs_cached")) return (int64_t)c->graphs.size();
+    return -1;
 }
 
 // ------------------------------------------------------------------------------------------------ timing

@@ -14,7 +14,8 @@
 //            P comes back from a wave-private LDS patch (consecutive probabilities per lane)
 //   combine  (m, l, O) of the 4 waves x KPN key groups through LDS, one pass.
 // The new key / value are used from LDS, so nothing depends on in-launch global visibility.
-// slot = T0 + *step is read from device memory so the same launch can be replayed from a hipGraph.
+// slot = T0 + *step: both are read from device memory (d_step = {step, T0}) so the same launch can be replayed from a hipGraph
+// for any step of any prompt length.
 // Latency chain (round 3).  The kernel is one wave of workgroups whose time is a chain of dependent memory round trips, not
 // bytes.  Two links are gone: (1) key tiles are indexed by ABSOLUTE cache slot (tile t = slots 32 t .. 32 t + 31, masked to
 // kstart[b] <= slot < T0 + step afterwards), so the first tile's K / V addresses depend on nothing the kernel has to load and
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         // work below runs underneath instead of behind them
         if (32 * wave < p.ctx_cap) load_tile(wave);
         __builtin_amdgcn_sched_barrier(0);
-        slot = p.T0 + *(cint_p)p.step;
+        slot = (p.T0 >= 0 ? p.T0 : ((cint_p)p.step)[1]) + ((cint_p)p.step)[0];   // (T0 < 0: prompt length from d_step[1] - a captured step serves any T)
         kstart = ((cint_p)p.kstart)[b];
         finish_rstd();
         // projection output rounded to fp16, as the unfused GEMM stores it

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float *__restrict_
     for (int j = 0; j < BEAM_MAXM; ++j) { bs[j] = -INFINITY; bi[j] = 0x7fffffff; }
     for (int k = 0; k < K; ++k) {
         const float *row = logits + (int64_t)(b * K + k) * V;
-        const float off = lse[b * K + k], add = run[b * K + k];
+        const float off = lse ? lse[b * K + k] : 0.f, add = run ? run[b * K + k] : 0.f;   // (both null: the plain top-M of a logits row)
         for (int v = tid; v < V; v += 256) {
             const float sc = (row[v] - off) + add;
             const int id = k * V + v;
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float *__restrict_
 // out_s = a of the drawn continuations (NOT the keys), out_i = k V + v, in the order drawn.
 __global__ __launch_bounds__(256) void beam_sample_kernel(const float *__restrict__ logits, const float *__restrict__ lse,
                                                           const float *__restrict__ run, const float *__restrict__ pmax,
-                                                          const float *__restrict__ thr, float inv_temp, uint64_t seed, int step,
+                                                          const float *__restrict__ thr, const float *__restrict__ kth, int min_keep,
+                                                          float inv_temp, uint64_t seed, int step,
                                                           int K, int V, int M, float *__restrict__ out_s, int32_t *__restrict__ out_i) {
     __shared__ float s_v[256];
     __shared__ int s_i[256];
@@ -126,11 +127,15 @@ __global__ __launch_bounds__(256) void beam_sample_kernel(const float *__restric
         for (int q = 1; q < APART; ++q) gmax = fmaxf(gmax, pmax[r * APART + q]);
         gmax *= inv_temp;                                            // (the expression of sample_stage1_kernel: the same p)
         const float off = lse[r], add = run[r], th = thr[r];
+        // min_tokens_to_keep of the warpers under beam-sample (#eos + 1, at least 2: GenerationMixin._get_logits_processor): the
+        // min_keep best tokens of a row stay whatever the nucleus says - kth[r][min_keep - 1] is the row's min_keep-th largest
+        // logit (ties with it stay too; the sorted-order cut of TopPLogitsWarper keeps exactly min_keep: a measure-zero difference)
+        const float lm = kth ? kth[r * min_keep + min_keep - 1] : INFINITY;
         const uint64_t h0 = splitmix64(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(r + 1)) ^ ((uint64_t)(step + 1) << 32));
         for (int v = tid; v < V; v += 256) {
             const float l = row[v];
             const float p = __expf(l * inv_temp - gmax);
-            if (!(p > th)) continue;
+            if (!(p > th) && !(l >= lm)) continue;
             const float a = (l - off) * inv_temp + add;
             const uint64_t h = splitmix64(h0 + 0xD1B54A32D192ED03ull * (uint64_t)(v + 1));
             const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
@@ -177,12 +182,18 @@ __global__ __launch_bounds__(256) void beam_sample_kernel(const float *__restric
     }
 }
 
+// min_keep > 1: kth_s / kth_i = scratch for the min_keep largest logits of each of the B K decoder rows (fp32 / int32 [B K min_keep])
 hipError_t launch_beam_sample(const float *logits, const float *run, int B, int K, int V, int M, float temperature, const float *pmax,
-                              const float *thr, uint64_t seed, int step, float *lse, float *out_s, int32_t *out_i, hipStream_t s) {
+                              const float *thr, int min_keep, float *kth_s, int32_t *kth_i, uint64_t seed, int step, float *lse,
+                              float *out_s, int32_t *out_i, hipStream_t s) {
     if (M < 1 || M > BEAM_MAXM || K < 1 || (int64_t)K * V >= 0x7fffffff || !(temperature > 0.f)) return hipErrorInvalidValue;
+    if (min_keep < 1 || min_keep > BEAM_MAXM || (min_keep > 1 && (!kth_s || !kth_i))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(beam_lse_kernel, dim3(B * K), dim3(256), 0, s, logits, V, lse);
-    hipLaunchKernelGGL(beam_sample_kernel, dim3(B), dim3(256), 0, s, logits, lse, run, pmax, thr, 1.0f / temperature, seed, step, K, V, M,
-                       out_s, out_i);
+    if (min_keep > 1)      // the min_keep best logits of every decoder row (the top-M kernel on single rows, no offsets)
+        hipLaunchKernelGGL(beam_topk_kernel, dim3(B * K), dim3(256), 0, s, logits, (const float *)nullptr, (const float *)nullptr, 1, V, min_keep,
+                           kth_s, kth_i);
+    hipLaunchKernelGGL(beam_sample_kernel, dim3(B), dim3(256), 0, s, logits, lse, run, pmax, thr, min_keep > 1 ? kth_s : (const float *)nullptr,
+                       min_keep, 1.0f / temperature, seed, step, K, V, M, out_s, out_i);
     return hipGetLastError();
 }
 
@@ -194,19 +205,27 @@ hipError_t launch_beam_topk(const float *logits, const float *run, int B, int K,
     return hipGetLastError();
 }
 
-// dst[r][:] = src[idx[r]][:] for R rows of `row_halfs` fp16 values (16-byte pieces; one layer's K or V cache rows)
-__global__ __launch_bounds__(256) void kv_gather_rows_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst,
-                                                             const int32_t *__restrict__ idx, int64_t row_halfs) {
-    const int r = blockIdx.y;
-    const h8 *s = reinterpret_cast<const h8 *>(src + (int64_t)idx[r] * row_halfs);
-    h8 *d = reinterpret_cast<h8 *>(dst + (int64_t)r * row_halfs);
-    const int64_t n8 = row_halfs >> 3;
+// One pass of the cache-row permutation of a beam step, on the FILLED slots only: a cache row is [kv head][slot][hd] with
+// `sub_halfs` between kv heads, of which slots 0 .. T0 + *step - 1 hold keys / values (the rest is never read before it is
+// written).  back = 0: tmp[r] = cache[idx[r]]; back = 1: cache[r] = tmp[r].  Rows that keep their place (idx[r] == r) are skipped
+// in both passes.  (Round 4 moved whole capacity-sized rows, 4 x the cache per step: advisor finding.)
+__global__ __launch_bounds__(256) void kv_gather_rows_kernel(half_t *__restrict__ cache, half_t *__restrict__ tmp,
+                                                             const int32_t *__restrict__ idx, int64_t row_halfs, int64_t sub_halfs,
+                                                             const int32_t *__restrict__ step, int T0, int hd, int back) {
+    const int r = blockIdx.y, sub = blockIdx.z;
+    const int from = idx[r];
+    if (from == r) return;
+    const int64_t n8 = ((int64_t)(T0 + *step) * hd) >> 3;
+    const h8 *s = reinterpret_cast<const h8 *>(back ? tmp + (int64_t)r * row_halfs + sub * sub_halfs : cache + (int64_t)from * row_halfs + sub * sub_halfs);
+    h8 *d = reinterpret_cast<h8 *>(back ? cache + (int64_t)r * row_halfs + sub * sub_halfs : tmp + (int64_t)r * row_halfs + sub * sub_halfs);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) d[i] = s[i];
 }
-hipError_t launch_kv_gather_rows(const half_t *src, half_t *dst, const int32_t *idx, int R, int64_t row_halfs, hipStream_t s) {
-    if (row_halfs & 7) return hipErrorInvalidValue;
-    const int gx = (int)((row_halfs >> 3) + 255) / 256;
-    hipLaunchKernelGGL(kv_gather_rows_kernel, dim3(gx > 64 ? 64 : gx, R), dim3(256), 0, s, src, dst, idx, row_halfs);
+hipError_t launch_kv_gather_rows(half_t *cache, half_t *tmp, const int32_t *idx, int R, int64_t row_halfs, int nsub, int64_t sub_halfs,
+                                 const int32_t *step, int T0, int hd, int back, hipStream_t s) {
+    if ((row_halfs & 7) || (sub_halfs & 7) || (hd & 7) || nsub < 1) return hipErrorInvalidValue;
+    const int gx = (int)((sub_halfs >> 3) + 255) / 256;
+    hipLaunchKernelGGL(kv_gather_rows_kernel, dim3(gx > 16 ? 16 : gx, R, nsub), dim3(256), 0, s, cache, tmp, idx, row_halfs, sub_halfs, step,
+                       T0, hd, back);
     return hipGetLastError();
 }
 

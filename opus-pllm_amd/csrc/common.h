@@ -317,8 +317,10 @@ hipError_t launch_beam_topk(const float *logits, const float *run, int B, int K,
 // beam-sample: M continuations per batch row drawn without replacement from softmax over the K filtered rows' accumulated
 // log-probabilities (thr: launch_sample_select's thresholds, pmax: its per-part maxima), in the order drawn
 hipError_t launch_beam_sample(const float *logits, const float *run, int B, int K, int V, int M, float temperature, const float *pmax,
-                              const float *thr, uint64_t seed, int step, float *lse, float *out_s, int32_t *out_i, hipStream_t s);
-hipError_t launch_kv_gather_rows(const half_t *src, half_t *dst, const int32_t *idx, int R, int64_t row_halfs, hipStream_t s);
+                              const float *thr, int min_keep, float *kth_s, int32_t *kth_i, uint64_t seed, int step, float *lse,
+                              float *out_s, int32_t *out_i, hipStream_t s);
+hipError_t launch_kv_gather_rows(half_t *cache, half_t *tmp, const int32_t *idx, int R, int64_t row_halfs, int nsub, int64_t sub_halfs,
+                                 const int32_t *step, int T0, int hd, int back, hipStream_t s);
 hipError_t launch_upload_i32(const int32_t *h, int n, int32_t *dst, hipStream_t s);   // host ints -> device through kernel arguments
 hipError_t launch_mask_to_kstart(const uint8_t *mask, int B, int T, int32_t *kstart, hipStream_t s);
 
@@ -336,8 +338,8 @@ struct AttnDecodeParams {
     int K;
     const float *bias;
     const float *cs_row;        // [B][hd / 2][2] (cos, sin) of each row's position in THIS step (written by the embedding kernel)
-    const int32_t *kstart, *step;
-    int T0, nh, nkv;
+    const int32_t *kstart, *step;   // step[0] = the step counter, step[1] = the prompt length T0 (api.cpp reset_step)
+    int T0, nh, nkv;                // T0 < 0: read step[1] (a captured decode step then serves any prompt length)
     half_t *kc, *vc;            // this layer's cache
     int64_t cache_sb, cache_sh;
     int ctx_cap;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void add_pos_kernel(float *__restrict__ x, con
                                                       const int32_t *__restrict__ kstart, const int32_t *__restrict__ step,
                                                       int t0, int Tq, int H, int max_idx) {
     const int row = blockIdx.x, b = row / Tq, tq = row % Tq;
-    const int slot = t0 + (step ? *step : 0) + tq;
+    const int slot = (t0 >= 0 ? t0 : step[1]) + (step ? step[0] : 0) + tq;      // (t0 < 0: the prompt length from the device, d_step[1])
     int idx = slot >= kstart[b] ? slot - kstart[b] + 2 : 1;
     idx = idx > max_idx ? max_idx : idx;
     for (int c = threadIdx.x; c < (H >> 3); c += 256) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t *__rest
     if (cnt && b == 0)
         for (int i = threadIdx.x; i < ncnt; i += 256) cnt[i] = 0;
     if (cs) {   // rotary (cos, sin) row of this batch row's position in this step, for every attention launch of the step
-        const int pos = T0 + *step - kstart[b];
+        const int pos = (T0 >= 0 ? T0 : step[1]) + step[0] - kstart[b];     // (T0 < 0: the prompt length from the device, d_step[1])
         for (int d = threadIdx.x; d < half; d += 256)
             reinterpret_cast<float2 *>(cs_row)[(int64_t)b * half + d] = reinterpret_cast<const float2 *>(cs)[(int64_t)pos * half + d];
     }

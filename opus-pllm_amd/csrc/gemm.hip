@@ -1725,6 +1725,9 @@ __global__ __launch_bounds__(256) void pp_tail_reduce_kernel(GemmParams p, int t
 template <int EPI>
 static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
     if (p_in.row_ssq) return hipErrorInvalidValue;                    // no row scale in this kernel's epilogue
+    // gemm_pp_kernel addresses A and W with 32-bit unsigned byte offsets: operands of 4 GiB and more are refused (launch_gemm_
+    // then falls back to the ring kernel's 64-bit addressing)
+    if ((int64_t)p_in.M * p_in.lda * 2 >= (1ll << 32) || (int64_t)p_in.N * p_in.K * 2 >= (1ll << 32)) return hipErrorInvalidValue;
     GemmParams p = p_in;
     // fused LayerNorm (GemmParams::ln_*): the consumer form must be honoured (the caller handed over un-normalised rows),
     // the producer form is best effort (*ln_done reports it)
@@ -1803,7 +1806,10 @@ static hipError_t launch_pp(const GemmParams &p_in, hipStream_t s) {
         }
     }
     // two k-parts: combined in the launch (gemm_pp_kernel); knob misc6 = 1: slabs + pp_tail_reduce_kernel as for more parts
-    const bool pair_mode = (!p.out_f32 && !p.residual) || (p.out_f32 && p.residual);   // the epilogue modes that carry the combine
+    // the epilogue modes that carry the combine (pp_epilogue's dispatch): fp16 output without a residual in every epilogue;
+    // fp32 output + fp32 residual in the plain epilogue only - with GELU / gate-up that combination runs the generic loop,
+    // which never reads the partner's half: such tiles go through the reduce kernel
+    const bool pair_mode = (!p.out_f32 && !p.residual) || (EPI == EPI_NONE && p.out_f32 && p.residual);
     const bool pair = split == 2 && p.combine_cnt && !g_knobs.misc[6] && pair_mode && (p.ldc & 7) == 0 && (p.ldr & 3) == 0 && (p.N & 255) == 0;
     if (!pair) p.combine_cnt = nullptr;
     OPUS_LAUNCH(KC_PP, kern, dim3(full + tail * split), dim3(512), 8 * 16384, s, p, bm, bn, full, split);
@@ -2313,7 +2319,9 @@ static hipError_t launch_tile_e(const GemmParams &p, hipStream_t s) {
     static const int min_tiles = getenv("OPUS_PP_MIN_TILES") ? atoi(getenv("OPUS_PP_MIN_TILES")) : 128;   // tuning aid (pp wins from about half a chip of tiles)
     if (!no_big && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= min_tiles) {   // enough 256 x 256 tiles to fill the chip
         static const bool no_pp = getenv("OPUS_NO_PP") != nullptr;          // A/B aid: single-phase ring kernels instead
-        if (no_pp) {
+        // gemm_pp_kernel addresses A and W with 32-bit byte offsets: operands of 4 GiB and more take the ring kernel (64-bit pointers)
+        const bool over4g = (int64_t)p.M * p.lda * 2 >= (1ll << 32) || (int64_t)p.N * p.K * 2 >= (1ll << 32);
+        if (no_pp || (over4g && !p.ln_stat)) {
             if ((p.residual || EPI == EPI_GELU) && p.K <= 4096) return launch_ring<4, 2, 4, EPI>(p, s, false);
             return launch_ring<8, 4, 4, EPI>(p, s, false);
         }

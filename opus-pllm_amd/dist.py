@@ -28,13 +28,14 @@ def split_between_processes(items: Sequence, rank: int, world: int) -> list:
     return list(items[lo:hi])
 
 
-def all_gather_ids(local: torch.Tensor, pad_id: int = 0, group=None) -> torch.Tensor:
+def all_gather_ids(local: torch.Tensor, pad_id: int = 0, group=None, force: bool = False) -> torch.Tensor:
     """local int tensor [B_local, N_local] (B_local and N_local may differ per rank) ->
     [sum B_local, max N] on every rank, rows in rank order, short rows padded with pad_id.
 
     Two collectives: an all-gather of the shapes (2 ints per rank) and one all-gather of the ids padded to
-    the common shape - with a ring over 8 xGMI-connected GPUs the 64 KB payload is latency-bound."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    the common shape - with a ring over 8 xGMI-connected GPUs the 64 KB payload is latency-bound.
+    force: run the collectives on a one-rank group too (tests/test_gpu_rccl.py: the RCCL code path on one GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     shape = torch.tensor([local.shape[0], local.shape[1]], dtype=torch.int64, device=local.device)
@@ -49,11 +50,11 @@ def all_gather_ids(local: torch.Tensor, pad_id: int = 0, group=None) -> torch.Te
     return torch.cat([o[:b] for o, (b, _) in zip(out, shapes)], dim=0)
 
 
-def all_gather_logits(local: torch.Tensor, group=None) -> torch.Tensor:
+def all_gather_logits(local: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
     """Optional parity dump (north_star "all-gather of logits"): fp32 [B_local, V] last-step logits of every
     rank -> [sum B_local, V] in rank order.  32.8 MB per rank at 64 x 128 256 - one all-gather over xGMI; B_local may differ
     per rank (the first n % world ranks hold one more row), so the rows are padded to the largest shard and trimmed."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     nrow = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)

@@ -293,6 +293,9 @@ class OpusLlamaForCausalLM:
         out_pos = None if position_ids is None else pos_out.to(dtype=position_ids.dtype)
         return None, out_pos, out_mask, past_key_values, emb, new_labels
 
+    # BASELINE.json's north_star calls the method by its short name; the reference defines only the long one (opus_arch.py:133)
+    prepare_inputs_for_multimodal = prepare_inputs_labels_for_multimodal
+
     # ------------------------------------------------------------------ rows G0, G1, D1-D4
     @torch.no_grad()
     def generate(self, inputs: Optional[torch.Tensor] = None, seq=None, seq_embedding=None, **kwargs) -> torch.LongTensor:
@@ -350,6 +353,11 @@ class OpusLlamaForCausalLM:
     # set it (run_opus_ddp.py:126-132), so 50 is what its sampling runs with.  generate(top_k=...) overrides per call; 0 / None = off.
     default_top_k = 50
 
+    # Beam-sample: the reference's pin, transformers 4.46.3, sorts the M sampled continuations of a row by score (descending)
+    # before its beam scorer looks at them, so "the first K may finish" means the K best of the draws; transformers >= 4.50
+    # (`_get_top_k_continuations`, the installed 5.15 the host tests compare with) keeps the order drawn.  True = the pin.
+    beam_sample_sorted = True
+
     def _set_top_k(self, k: int) -> None:
         if k != getattr(self, "_top_k", 0):
             _cabi.check(self._lib.opus_set_sampling_top_k(self._ctx, int(k)))
@@ -400,6 +408,9 @@ class OpusLlamaForCausalLM:
                     raise RuntimeError("invalid multinomial distribution (with replacement=False, not enough non-negative category "
                                        f"to sample): beam-sample draws {M} continuations per row, the temperature / top_k / top_p "
                                        "filters left fewer")        # (torch.multinomial's message: what the reference raises here)
+                if sampler is not None and self.beam_sample_sorted:     # 4.46.3: torch.sort(next_token_scores, descending=True) behind the draw
+                    order = np.argsort(-sc, axis=1, kind="stable")
+                    sc, ix = np.take_along_axis(sc, order, 1), np.take_along_axis(ix, order, 1)
                 tok, src, done = state.step(sc, ix)
                 if done:
                     break
@@ -535,6 +546,18 @@ class OpusLlamaForCausalLM:
         _cabi.check(self._lib.opus_timing_names(buf, 512))
         classes, phases = buf.value.decode().split(";")
         return classes.split(","), phases.split(",")
+
+    def drop_decode_graphs(self) -> None:
+        """Forget the captured decode steps of this context (measurement aid: what a capture + instantiation per batch costs)."""
+        _cabi.check(self._lib.opus_debug_knob(self._ctx, b"misc0", 0))
+
+    def stat(self, name: str) -> int:
+        """Counters of this context: "graph_instantiations" (decode-step hipGraphs instantiated: one per distinct batch size /
+        token budget / sampling setting, none per prompt length), "graph_replays", "graphs_cached"."""
+        v = int(self._lib.opus_stat(self._ctx, name.encode()))
+        if v < 0:
+            raise KeyError(name)
+        return v
 
     def last_logits(self, B: int) -> torch.Tensor:
         """fp32 [B, V] logits of the most recent prefill / decode step (the optional logits gather of SURVEY 8e)."""

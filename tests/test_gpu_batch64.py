@@ -304,6 +304,100 @@ def test_full_width_two_layer_batch64_vs_oracle(dev):
         torch.cuda.empty_cache()
 
 
+def test_full_width_two_layer_c5_vs_oracle(dev):
+    """configs[4] PINNED at its widths (round-4 review: C5 was exercised, not pinned): every kernel of the C5 path at its real
+    width - ESM2-t36-3B encoder (2560-d, 40 heads x 64, FFN 10 240), 5120 -> 40 960 -> 40 960 projectors, Vicuna-13B decoder
+    (5120-d, 40 MHA heads x 128, FFN 13 824: gemm_stream at 5 panels x 4 k-parts, V = 32 000) - against the fp32 oracle, on
+    2 + 2 layers, 32 proteins of 600 - 1024 residues (token-packed encoder, 26 k token rows), exactly as the Llama-3-8B widths
+    are pinned above: pooled / tokens / logits bounds, greedy ids equal on decisive steps."""
+    import oracle
+    cfg = opa.OpusConfig(enc_layers=2, enc_dim=2560, enc_heads=40, enc_ffn=10240, proj_dim=5120,
+                         dec_layers=2, dec_dim=5120, dec_heads=40, dec_kv_heads=40, dec_head_dim=128, dec_ffn=13824,
+                         dec_vocab=32000, dec_rope_theta=10000.0, max_batch=32, max_enc_tokens=1026, max_prompt=56,
+                         max_new_tokens=8).validate()
+    model = _model(cfg, dev)
+    try:
+        W = LazyCanon(cfg, 0, dev, keep_bytes=20e9)
+        pipe = oracle.OraclePipeline(cfg, W)
+        lengths = [600 + (53 * i) % 425 for i in range(32)]
+        assert min(lengths) >= 600 and max(lengths) <= 1024
+        seqs = [synth.synth_protein(n, 900 + i) for i, n in enumerate(lengths)]
+        ids = _prompts(cfg, 32, n_text=41)
+        mask = torch.ones_like(ids, dtype=torch.bool)
+        with torch.no_grad():
+            pooled_ref = pipe.encode_seq2embedding(seqs)
+            prot_ref = pipe.switch_projector_embedding(pipe.encode_projector_embedding(pooled_ref))
+        pooled = model.encode_seq2embedding(seqs)
+        prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+        obs = dict(pooled=rel_l2(pooled, pooled_ref), prot=rel_l2(prot.float(), prot_ref))
+        assert obs["pooled"] < ORACLE_POOLED and obs["prot"] < ORACLE_PROT, obs
+        with torch.no_grad():
+            ref_ids, margins, ref_logits = pipe.generate(ids, seqs, mask, 5, (), 0)
+        out = model.generate(ids, seqs, attention_mask=mask, pad_token_id=0, do_sample=False, max_new_tokens=5)
+        n_ok = n_all = 0
+        for b in range(32):
+            low = (margins[b] < MARGIN_TAU).nonzero()
+            n = int(low[0]) if len(low) else 5
+            assert torch.equal(out[b, :n].cpu(), ref_ids[b, :n]), (b, out[b], ref_ids[b], margins[b])
+            n_ok += n
+            n_all += 5
+        obs["ids_checked_fraction"] = n_ok / n_all
+        emb, mo, _ = model._splice(ids, mask, prot, True)
+        got = _teacher_forced(model, emb, mo, ref_ids[:, :3].to(dev))
+        obs["logits"] = [rel_l2(got[s], ref_logits[s]) for s in range(4)]
+        record("full_width_c5_vs_oracle", obs)
+        assert max(obs["logits"]) < ORACLE_LOGITS, obs
+        assert obs["ids_checked_fraction"] >= 0.9, obs         # 147 of 160 ids lie before their row's first near-tie (a property of fixture + oracle)
+    finally:
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_b64_full_depth_rows_vs_oracle(big64):
+    """Batch 64 at FULL DEPTH against the oracle on rows other than row 0 (round-4 review: batch-64-at-depth met the oracle only
+    through row 0 alone + row-vs-batch transitivity): the exact C4 shard (64 x 512 residues, 33 + 32 layers) runs on the GPU, the
+    oracle runs rows 17 and 42 (one pass of batch 2, weights streamed layer by layer): pooled embedding, protein tokens, prefill
+    logits and 2 teacher-forced decode steps of THOSE ROWS OF THE BATCH."""
+    import oracle
+    from oracle.llama import llama_forward
+    cfg, model = big64
+    dev = model.device
+    rows = [17, 42]
+    seqs = [synth.synth_protein(512, i) for i in range(64)]
+    ids = _prompts(cfg, 64)
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    pooled = model.encode_seq2embedding(seqs)
+    prot = model.switch_projector_embedding(model.encode_projector_embedding(pooled))
+    emb, mo, _ = model._splice(ids, mask, prot, True)
+    lg0 = model.prefill_logits(emb, mo)
+    toks, got = [lg0.argmax(-1)], [lg0]
+    for _ in range(2):
+        got.append(model.decode_logits(toks[-1]))
+        toks.append(got[-1].argmax(-1))
+    forced = torch.stack(toks[:2], 1).cpu()                                  # [64, 2]
+    W = LazyCanon(cfg, 0, dev, keep_bytes=5e9)
+    pipe = oracle.OraclePipeline(cfg, W)
+    sub = [seqs[r] for r in rows]
+    with torch.no_grad():
+        pooled_ref = pipe.encode_seq2embedding(sub)
+        prot_ref = pipe.switch_projector_embedding(pipe.encode_projector_embedding(pooled_ref))
+        emb_ref, m_ref, _, _ = oracle.splice_and_pad(ids[rows], mask[rows], prot_ref, W["dec.embed_tokens"], True)
+        full = torch.cat([emb_ref, W["dec.embed_tokens"][forced[rows]]], dim=1)
+        fmask = torch.cat([m_ref, torch.ones(len(rows), 2, dtype=torch.bool)], dim=1)
+        T = emb_ref.shape[1]
+        ref = llama_forward(full, fmask, W, cfg, all_logits=True)[0][:, T - 1:]          # [2, 3, V]
+    obs = dict(pooled=rel_l2(pooled[rows], pooled_ref), prot=rel_l2(prot[rows].float(), prot_ref),
+               logits=[rel_l2(got[s][rows], ref[:, s]) for s in range(3)])
+    obs["margins"] = [[float(_margin(ref[i:i + 1, s])) for s in range(3)] for i in range(len(rows))]
+    record("b64_full_depth_rows_vs_oracle", obs)
+    assert obs["pooled"] < ORACLE_POOLED and obs["prot"] < ORACLE_PROT, obs
+    assert max(obs["logits"]) < ORACLE_LOGITS, obs
+    for i, r in enumerate(rows):
+        for s in range(3):
+            if obs["margins"][i][s] > MARGIN_TAU:
+                assert int(got[s][r].argmax()) == int(ref[i, s].argmax()), (r, s, obs)
+
+
 def test_c2_full_depth_vs_oracle(big64):
     """The exact C2 model (ESM2-650M shape x 33 layers, 1.24 B projector, Llama-3-8B shape x 32 layers), one 512-residue
     protein, against the fp32 oracle: pooled embedding, protein tokens, prefill logits and 3 teacher-forced decode steps.
@@ -710,7 +804,7 @@ def test_beam_sample_step_at_full_width(big64, B, K, M):
         _cabi.check(lib.opus_beam_sample_topk(model._ctx, None, d_run.data_ptr(), B, K, M, t, p, 11, step, sc.data_ptr(), ix.data_ptr(), None))
         s, i = sc.cpu(), ix.cpu().long()
         for b in range(B):
-            ref = oracle.beam_sample_distribution(lg[b * K:(b + 1) * K], run[b], t, p, 50)
+            ref = oracle.beam_sample_distribution(lg[b * K:(b + 1) * K], run[b], t, p, 50, M // K)
             assert bool((ref[i[b]] > 0).all()), (b, step)
             assert len(set(i[b].tolist())) == M
             d = s[b] - torch.log(ref[i[b]])

@@ -97,6 +97,10 @@ def test_synthetic_fill_matches_numpy_twin(dev):
     # 384 tiles = 1.5 rounds with a long K: the 128 tail tiles are cut in TWO k-parts, combined inside the launch (the half that
     # arrives second adds the first one's accumulators and runs the kernel's own epilogue): fp32 + residual, GELU fp16, gate/up
     (6144, 4096, 4096, 0, 1, True), (3072, 8192, 3072, 1, 0, False), (3072, 16384, 3072, 2, 0, False),
+    # 630 tiles, 118 tail tiles in two k-parts with GELU + fp32 output + residual: the epilogue mode WITHOUT an in-launch pair
+    # combine - these tiles must go through pp_tail_reduce_kernel (round-4 advisor finding: the launcher sent them to the pair path
+    # and half of K was lost; not on the product path, whose GELU output is fp16)
+    (16000, 2560, 2560, 1, 1, True),
 ])
 def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
     """Both GEMM kernels (skinny M<=64, tile M>64), every epilogue, ragged M/N, vs fp64 on fp16 operands."""
@@ -593,6 +597,53 @@ def test_generate_beam_golden(dev, gold, gold_dir):
         model.generate(ids, seqs, attention_mask=mask, num_beams=0, max_new_tokens=4)
 
 
+def test_decode_graph_is_shared_across_prompt_lengths(dev, monkeypatch):
+    """The reference's loop brings a new prompt length with every batch (eval/run_opus_ddp.py:88-135).  The captured decode step
+    reads T0 from device memory, so batches of one size share ONE instantiated hipGraph whatever their T: counted here, with
+    the ids of every batch equal to eager launches of the same batch.  A different number of rows is another graph (kept beside
+    the first: going back to the first size instantiates nothing); more than four sizes evict the least recently used."""
+    cfg = opa.micro(max_prompt=80, max_new_tokens=16)
+    model, _ = make_model(cfg, dev)
+    seqs = [synth.synth_protein(20 + 3 * i, i) for i in range(6)]
+
+    def batch(B, n_text, ragged):
+        rows = [synth.synth_prompt_ids(cfg.dec_vocab, 7 * i + n_text, n_text=n_text - (3 * i if ragged else 0), seq_pos=4) for i in range(B)]
+        width = max(len(r) for r in rows)
+        ids = torch.full((B, width), 2, dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, width - len(r):] = torch.tensor(r)
+        return ids, ids != 2
+
+    def run(B, n_text, ragged=False):
+        ids, mask = batch(B, n_text, ragged)
+        return model.generate(ids, seqs[:B], attention_mask=mask, pad_token_id=2, do_sample=False, max_new_tokens=12).cpu()
+
+    assert model.stat("graph_instantiations") == 0
+    outs = {}
+    for n_text in (20, 35, 64, 21, 50):                           # T = 27 .. 71: five different prompt lengths, 4 rows
+        outs[n_text] = run(4, n_text, ragged=n_text % 2 == 0)
+    assert model.stat("graph_instantiations") == 1, model.stat("graph_instantiations")
+    assert model.stat("graph_replays") >= 5 * 10 - 1              # (the very first step of the first batch runs eagerly)
+    short = run(3, 40)                                            # the short last batch of a dataset: its own graph
+    assert model.stat("graph_instantiations") == 2
+    again = run(4, 35, ragged=False)                              # back to the first size: cached
+    assert model.stat("graph_instantiations") == 2 and model.stat("graphs_cached") == 2
+    assert torch.equal(again, outs[35])
+    monkeypatch.setenv("OPUS_NO_GRAPH", "1")
+    for n_text in (20, 35, 64, 21, 50):
+        assert torch.equal(run(4, n_text, ragged=n_text % 2 == 0), outs[n_text]), n_text
+    assert torch.equal(run(3, 40), short)
+    monkeypatch.delenv("OPUS_NO_GRAPH")
+    n0 = model.stat("graph_instantiations")
+    for B in (1, 2, 5, 6):                                        # four more sizes: the cache holds four graphs
+        run(B, 30)
+    assert model.stat("graph_instantiations") == n0 + 4 and model.stat("graphs_cached") == 4
+    run(4, 30)                                                    # evicted meanwhile: instantiated again
+    assert model.stat("graph_instantiations") == n0 + 5
+    with pytest.raises(KeyError):
+        model.stat("no_such_counter")
+
+
 def test_generate_stop_sequence_opt_in(micro, gold, gold_dir):
     """Row N2, "### early-stop as an opt-in": with a stop sequence set, a row is finished once its new ids end with it and
     emits pad afterwards; the ids up to and including the sequence are the free-running ones, rows that never produce it are
@@ -698,9 +749,14 @@ def test_beam_sample_draws_match_hf_distribution(micro, dev):
                                               ix.data_ptr(), None))
         return sc.cpu(), ix.cpu().long()
 
-    for t, p, k, run in ((1.0, 0.9, 0, [0.0, -0.7]), (1.5, 1.0, 6, [-0.3, 0.0]), (0.8, 0.95, 50, [0.0, -1.0e9])):
+    # (the fourth setting is the reference's default sampler, temperature 0.1 / top_p 0.7 / top_k 50: the nucleus alone is ONE token
+    #  per beam; the second one stays through the warpers' min_tokens_to_keep = M / K = 2 - exactly M continuations are left)
+    for t, p, k, run in ((1.0, 0.9, 0, [0.0, -0.7]), (1.5, 1.0, 6, [-0.3, 0.0]), (0.8, 0.95, 50, [0.0, -1.0e9]), (0.1, 0.7, 50, [0.0, -0.7]),
+                         (0.1, 0.7, 1, [-0.2, 0.0])):
         model._set_top_k(k)
-        ref = oracle.beam_sample_distribution(base, torch.tensor(run), t, p, k)
+        ref = oracle.beam_sample_distribution(base, torch.tensor(run), t, p, k, M // K)
+        if t == 0.1:
+            assert int((ref > 0).sum()) == M
         lp = torch.log(ref)                                              # accumulated log-probabilities up to the common normaliser
         first, second = torch.zeros(K * V), torch.zeros(K * V)
         for step in range(500):

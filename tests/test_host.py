@@ -26,7 +26,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _cabi.lib()                          # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 9 and lib.opus_operand_dtype() == 0
+    assert lib.opus_abi_version() == _cabi.ABI_VERSION == 10 and lib.opus_operand_dtype() == 0
     # pure host entry points that need no GPU
     cc = _cabi.CConfig.from_config(opa.llama3_8b())
     assert lib.opus_workspace_bytes(ctypes.byref(cc)) > 1 << 30
@@ -161,6 +161,29 @@ def test_no_cpu_fallback():
     from opus_pllm_amd.model import OpusLlamaForCausalLM
     with pytest.raises(_cabi.OpusError):
         OpusLlamaForCausalLM(opa.micro(), None, "cpu")
+
+
+def test_short_method_name_of_the_north_star_is_an_alias():
+    """BASELINE.json's north_star names prepare_inputs_for_multimodal(); the reference's method is
+    prepare_inputs_labels_for_multimodal (opus_arch.py:133): both names reach the same function."""
+    from opus_pllm_amd.model import OpusLlamaForCausalLM as M
+    assert M.prepare_inputs_for_multimodal is M.prepare_inputs_labels_for_multimodal
+
+
+def test_roofline_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py reports the committed PMC passes as `roofline.traffic` only while the kernel sources hash to what the passes were
+    taken on; it picks the newest round's file."""
+    import json
+    import bench
+    sha = bench.sources_sha16()
+    assert len(sha) == 16 and sha == bench.sources_sha16()
+    f = bench.newest_pmc_summary(64)
+    assert f is not None and os.path.basename(f).startswith("r") and f.endswith("_pmc_traffic_b64.json")
+    rounds = sorted(int(os.path.basename(p_)[1:3]) for p_ in __import__("glob").glob(os.path.join(os.path.dirname(f), "r*_pmc_traffic_b64.json")))
+    assert int(os.path.basename(f)[1:3]) == rounds[-1]
+    assert bench.newest_pmc_summary(7) is None
+    doc = json.load(open(f))
+    assert "classes" in doc and "gemm_pp" in doc["classes"]
 
 
 # ------------------------------------------------------------------------------------------------ N2: prompt front-ends

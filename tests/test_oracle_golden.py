@@ -193,6 +193,22 @@ def test_sampling_distribution_restates_hf_warpers():
     for t, p, k in ((0.7, 0.7, 50), (1.3, 0.95, 5), (2.0, 1.0, 20), (1.0, 0.9, 1), (1.0, 0.8, 400)):
         hf = TopPLogitsWarper(p)(None, TopKLogitsWarper(k)(None, TemperatureLogitsWarper(t)(None, logits))).softmax(-1)
         assert torch.allclose(oracle.sampling_distribution(logits, t, p, k), hf, atol=1e-7), (t, p, k)
+    # beam-sample: GenerationMixin._get_logits_processor builds both warpers with min_tokens_to_keep = #eos + 1 (2 without an EOS
+    # id) when num_beams > 1 and applies them to log_softmax / temperature; at the reference's defaults (0.1 / 0.7) the nucleus
+    # alone is a single token, the second one survives through min_tokens_to_keep (round-4 advisor finding)
+    from oracle.sampling import _warp
+    lp = torch.log_softmax(logits, -1)
+    for t, p, k, m in ((0.1, 0.7, 50, 2), (0.1, 0.7, 0, 2), (0.7, 0.7, 1, 2), (1.3, 0.95, 5, 3), (0.1, 0.3, 50, 3)):
+        x = TemperatureLogitsWarper(t)(None, lp)
+        if k:
+            x = TopKLogitsWarper(k, min_tokens_to_keep=m)(None, x)
+        hf = TopPLogitsWarper(p, min_tokens_to_keep=m)(None, x)
+        mine = _warp(lp / t, p, k, m)
+        assert torch.equal(torch.isinf(mine), torch.isinf(hf)), (t, p, k, m)
+        assert int((~torch.isinf(hf)).sum(-1).min()) >= m
+        run = torch.tensor([0.0, -0.3, -1.1, -2.0])
+        want = (hf + run[:, None]).reshape(-1).softmax(-1)
+        assert torch.allclose(oracle.beam_sample_distribution(logits, run, t, p, k, m), want, atol=1e-7), (t, p, k, m)
 
 
 @pytest.mark.parametrize("tag,preset", [("generate_micro_opt", "micro_opt"), ("generate_micro_opt_relu", "micro_opt_relu"),

@@ -90,6 +90,14 @@ def main():
         result["not_step_traffic"] = {k: {"launches": n, "fabric_bytes": b} for k, (b, n) in apart.items()}
         result["note"] = ("fabric = L2<->fabric bytes (TCC_EA0 read requests, gfx950-corrected, + WRITE_SIZE): Infinity-Cache hits "
                           "are counted; algorithmic = operands / weights once + activations + outputs (bench.py roofline block)")
+    # which kernels these counters belong to: bench.py reports them as `roofline.traffic` only while the sources still hash to this
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_opus_build", os.path.join(root, "opus-pllm_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    result["csrc_sha16"] = mod.sources_sha16()
     json.dump(result, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
 
