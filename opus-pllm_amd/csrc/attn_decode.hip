@@ -345,6 +345,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 
     // The new key / value (fed from LDS: nothing depends on in-launch global visibility) takes its place - cache slot `slot` -
     // in the tile that slot belongs to: no separate one-key tile on top of one wave's share (that wave was the critical path).
+    // (measured and not kept, round 5: the wave's next tile (t + 4) requested into a second register set before the current one is
+    //  multiplied - 256 instead of 196 VGPRs, still 2 waves per SIMD - for contexts of 128 - 352 slots: attn_decode 173.0 / 174.0 ms
+    //  per 256-token step with the prefetch against 170.9 / 168.8 with the loads just before their use in the same build, and 133.3 ms
+    //  for this single-set form (profiles/r05_decode_ab.txt).  With 512 workgroups x 4 waves every CU already has 8 tile loads in
+    //  flight; the kernel moves its 59 MB of K / V per launch in ~11 us (5.5 TB/s) + ~5 us of fixed cost - queue depth is not its limit.)
     for (int t = t_first + wave; t <= t_new; t += 4) {
         if (t != wave) load_tile(t);                 // (the tile requested at entry is the right one unless the row is padded by >= 32)
         const int lo = kstart - 32 * t;

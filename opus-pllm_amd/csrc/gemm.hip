@@ -26,7 +26,17 @@
 namespace opus {
 
 thread_local LaunchEvents *tl_launch_ev = nullptr;
-Knobs g_knobs;
+// OPUS_KNOB_MISC<i>=<int> presets the scratch knobs (A/B runs of whole bench.py steps; opus_debug_knob changes them at run time)
+static Knobs knobs_from_env() {
+    Knobs k;
+    for (int i = 0; i < 8; ++i) {
+        char name[32];
+        snprintf(name, sizeof(name), "OPUS_KNOB_MISC%d", i);
+        if (const char *v = getenv(name)) k.misc[i] = atoi(v);
+    }
+    return k;
+}
+Knobs g_knobs = knobs_from_env();
 
 hipError_t ensure_dyn_lds(const void *fn, size_t bytes) {
     static std::mutex mu;

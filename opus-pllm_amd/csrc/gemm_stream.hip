@@ -298,6 +298,13 @@ static bool stream_plan(int M, int N, int K, bool slab_only, bool a_tiled, int64
     //  workgroup, 448 workgroups in 1.75 rounds, silu(g) u + the row scale in the combine - parity-green and 58 us per launch against
     //  gemm_wide_kernel's 45.8: every workgroup re-reads the whole activation matrix from L2, 229 MB beside 235 MB of weights, and a
     //  CU's L1 takes in ~67 GB/s)
+    // (measured and not kept, round 5, profiles/r05_decode_ab.txt - the 2-D plans the round-4 review asked about for the wo projection
+    //  at 64 rows, isolated, fragment-ordered A: this planner's 1 panel x whole K 13.7 us; 4 panels x 4 k-parts (as down) 15.7 us - a
+    //  quarter of the activation bytes per CU, but 16 chunks over 8 waves leave two chunks per wave and the slabs + ticket cost more than
+    //  the L1 intake they relieve; 2 panels x 2 k-parts 13.05 us (-5 %: 0.65 us per layer, 0.3 % of the step) - not taken: it would
+    //  either break "a row's result does not depend on the rows that share its launch" between <= 16 and > 16 rows or need the pair
+    //  plan at every row count.  down as 2 x 2 instead of 4 x 4: 31.2 vs 28.3 us - its 917 KB of activations per CU are back at the
+    //  L1 limit.  In the step: 249.8 / 250.7 ms (planner) vs 252.7 / 252.9 (wo 4 x 4) vs 251.8 / 251.7 (wo and down 2 x 2).)
     for (auto &c : cand) {
         const int P = c[0], ks = c[1];
         if (npanels % P) continue;

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace -d gpurun_out/gaps -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-c2 --no-inflight --no-e2e > gpurun_out/gaps.log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/gaps -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-c2 --no-inflight --no-e2e --no-var-t > gpurun_out/gaps.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/gaps/**/*kernel_trace.csv", recursive=True)[0]
