@@ -121,7 +121,8 @@ int opus_esm2_encode(opus_ctx *ctx, const int32_t *d_tokens, const int32_t *d_le
  * to back, h_cu (HOST) int32 [B + 1] their row offsets (cu[0] = 0; 2 <= cu[b+1] - cu[b] <= max_enc_tokens;
  * cu[B] <= max_batch * max_enc_tokens) -> pooled fp32 [B, enc_dim], the same values as opus_esm2_encode gives each protein
  * (different GEMM tile boundaries: equal to the tolerance of DESIGN.md section 3, not bitwise).  Mixed lengths need no buckets.
- * opus_esm2_last_hidden(ctx, out, 1, cu[B]) then returns the packed [cu[B], enc_dim] representations. */
+ * opus_esm2_last_hidden(ctx, out, 1, cu[B]) then returns the packed [cu[B], enc_dim] representations of the RESIDUE rows; the
+ * <cls> / <eos> rows, which the mean-pool drops, are not computed by the last layer (knob "enc_full_last_layer" = 1: they are). */
 int opus_esm2_encode_packed(opus_ctx *ctx, const int32_t *d_tokens, const int32_t *h_cu, int32_t B, float *d_pooled, void *stream);
 /* Debug/parity tap: copy of representations[enc_layers] fp32 [B,T,enc_dim] of the last encode. */
 int opus_esm2_last_hidden(opus_ctx *ctx, float *d_out, int32_t B, int32_t T, void *stream);
@@ -204,7 +205,8 @@ int opus_debug_gemm_slabs(opus_ctx *ctx, const void *d_A, const void *d_W, float
 /* Process-wide tuning knob of the benchmarks / parity tests (no reference counterpart): "no_stream" = 1 routes the narrow
  * GEMMs of the batched decode step through the round-2 split-K kernels instead of gemm_stream_kernel; "pp_gm" = tile rows
  * per rasterisation group of the big tiled GEMM; "debug_a_tiled" = 1: opus_debug_gemm takes A in fragment order; "no_ln_fusion" = 1: stand-alone normalisation kernels
- * instead of the norms fused around the big tiled GEMM; "poison_handoff" = 1 (needs ctx): leaves the hand-off words as an
+ * instead of the norms fused around the big tiled GEMM; "enc_full_last_layer" = 1: the token-packed encoder's last layer computes
+ * the <cls> / <eos> rows as well; "poison_handoff" = 1 (needs ctx): leaves the hand-off words as an
  * aborted launch would (test aid); "misc0".."misc7" scratch.  ctx (may be NULL) drops its captured decode graph. */
 int opus_debug_knob(opus_ctx *ctx, const char *name, int32_t value);
 /* The row-scale RMSNorm fusion as the decoder issues it (api.cpp prefill / decode_step): X <- X + A W1^T through a GEMM

@@ -678,6 +678,10 @@ static int esm2_encode_rows(opus_ctx *c, hipStream_t s, const int32_t *d_tokens,
         a.O = c->e_ctx; a.o_sb = packed ? 0 : (int64_t)T * D; a.o_st = D;
         a.kstart = nullptr; a.kend = packed ? nullptr : d_lens; a.cu = d_cu;
         a.B = B; a.T = T; a.heads = nh; a.group = 1; a.head_dim = hd; a.causal = 0; a.scale = 1.0f;
+        // last layer: the <cls> / <eos> rows of representations[L] are dropped by the mean-pool (cstp_v3/modelling.py:52-54): they
+        // are keys but not queries (512 residues: four query blocks instead of five).  The debug tap opus_esm2_last_hidden then
+        // holds no representation in those rows; knob "enc_full_last_layer" = 1 computes them (parity tests of every token's state).
+        a.q_trim = packed && l + 1 == g.enc_layers && T > 2 && !g_knobs.enc_full_last_layer ? 1 : 0;
         KLF(KC_ATTN_PREFILL, 8.0 * M * D, attn_flops, launch_attn_prefill(a, s));
         if (fc1_pp) { c->rq_ln_part = c->e_part; c->rq_ln_xh = c->e_xn; }
         OPC(gemm(c, s, c->e_ctx, D, L.wo, M, D, D, L.bo, EPI_NONE, c->e_x, c->e_x, D, 1));
@@ -1589,6 +1593,7 @@ extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
     if (!strcmp(name, "no_stream")) g_knobs.no_stream = value;
     else if (!strcmp(name, "debug_a_tiled")) g_knobs.debug_a_tiled = value;
     else if (!strcmp(name, "no_ln_fusion")) g_knobs.no_ln_fusion = value;
+    else if (!strcmp(name, "enc_full_last_layer")) g_knobs.enc_full_last_layer = value;
     else if (!strcmp(name, "poison_handoff")) {   // test aid: what an aborted launch leaves behind - every ticket drawn once, no flag set
         if (!c) return fail(OPUS_EBADARG, "poison_handoff needs a context");
         std::vector<int32_t> h(HANDOFF_ERR, 0);

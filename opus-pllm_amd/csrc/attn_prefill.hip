@@ -81,20 +81,25 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     // Workgroup ids are dealt round-robin over the 8 XCDs: ids that are equal mod 8 share an L2.  All query blocks of one
     // (batch, head) - which stream the same K / V - therefore take ids of one residue class: K / V come from HBM / the
     // Infinity Cache once per (batch, head) instead of once per query block.  (Placement is a speed matter only.)
-    const int nqb = (p.T + QB - 1) / QB;
+    // AttnParams::q_trim (token-packed batches only): the first and the last token of every row are not queries - the last ESM-2
+    // layer, whose <cls> / <eos> rows the mean-pool drops (cstp_v3/modelling.py:52-54): 512 residues are then four query blocks of
+    // 128 instead of five, the fifth holding the last residue and <eos>.  Keys are untouched; the trimmed rows of O keep what they held.
+    const int qtrim = (p.q_trim && p.cu) ? 1 : 0;
+    const int nqb = (p.T - 2 * qtrim + QB - 1) / QB;
     const int id = blockIdx.x, slot = id >> 3;
     const int bh = (slot / nqb) * 8 + (id & 7);
     if (bh >= p.B * p.heads) return;
     const int b = bh / p.heads, h = bh % p.heads, hk = h / p.group;
-    const int q0 = (slot % nqb) * QB, qw = q0 + wave * QW;
+    const int q0 = (slot % nqb) * QB + qtrim, qw = q0 + wave * QW;
     // token-packed batch (AttnParams::cu): this row's tokens are rows cu[b] .. cu[b + 1] - 1 of Q / K / V / O, all of them
     // visible keys; query blocks past the row's last token (the grid is sized by the longest row) leave at once
-    int T = p.T;
+    int T = p.T, Tq = p.T;                                            // Tq: end of the query range
     int64_t qb_off = (int64_t)b * p.q_sb, kb_off = (int64_t)b * p.k_sb, vb_off = (int64_t)b * p.v_sb, ob_off = (int64_t)b * p.o_sb;
     if (p.cu) {
         const int r0 = p.cu[b];
         T = p.cu[b + 1] - r0;
-        if (q0 >= T) return;                                          // (uniform, before any barrier)
+        Tq = T - qtrim;
+        if (q0 >= Tq) return;                                         // (uniform, before any barrier)
         qb_off = (int64_t)r0 * p.q_st; kb_off = (int64_t)r0 * p.k_st; vb_off = (int64_t)r0 * p.v_st; ob_off = (int64_t)r0 * p.o_st;
     }
     const int kstart = (p.kstart && !p.cu) ? p.kstart[b] : 0;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         int qr = qw + 16 * t + li;
-        qr = qr < T ? qr : T - 1;
+        qr = qr < Tq ? qr : Tq - 1;
         const half_t *src = Qb + (int64_t)qr * p.q_st;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         k_hi = k_hi < last_q + 1 ? k_hi : last_q + 1;
     }
     const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
-    const bool wave_live = qw < T;                  // waves past the last query only help with the tile staging
+    const bool wave_live = qw < Tq;                 // waves past the last query only help with the tile staging
 
     // K/V tiles: global -> registers one tile ahead of the LDS copy
     constexpr int KL = KB * CH / 256;            // 16-B pieces of K per thread and tile
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const int qi = qw + 16 * t + li;
-        if (qi >= T) continue;
+        if (qi >= Tq) continue;
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         half_t *dst = p.O + ob_off + (int64_t)qi * p.o_st + (int64_t)h * HD;
 #pragma unroll
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 
 template <int HD, int QT>
 static hipError_t launch_qt(const AttnParams &p, hipStream_t s) {
-    const int nqb = cdiv(p.T, 64 * QT);
+    const int nqb = cdiv(p.T - ((p.q_trim && p.cu) ? 2 : 0), 64 * QT);
     dim3 grid(((p.B * p.heads + 7) / 8) * 8 * nqb);
     if (p.causal) OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, true, QT>), grid, dim3(256), 0, s, p);
     else OPUS_LAUNCH(KC_ATTN_PREFILL, (attn_prefill_kernel<HD, false, QT>), grid, dim3(256), 0, s, p);

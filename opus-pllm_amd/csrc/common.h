@@ -194,6 +194,7 @@ struct AttnParams {
     // back with no padding (q_sb / k_sb / v_sb / o_sb unused).  Row b has cu[b + 1] - cu[b] tokens, all of them visible keys
     // (kstart / kend unused); T = the longest row (sizes the grid).
     const int32_t *cu = nullptr;
+    int q_trim = 0;         // token-packed only: 1 = the first and the last token of every row are keys but not queries (last ESM-2 layer)
 };
 
 hipError_t launch_gemm(const GemmParams &p, hipStream_t s, int *klass);
@@ -208,6 +209,7 @@ struct Knobs {
     int no_ln_fusion = 0;   // 1: stand-alone normalisation kernels instead of the norms fused around gemm_pp_kernel
     int debug_a_tiled = 0;  // 1: opus_debug_gemm takes A in fragment order (GemmParams::a_tiled)
     int pp_gm = 8;          // tile-rows per group of the gemm_pp / gemm_ring rasterisation
+    int enc_full_last_layer = 0;   // 1: the packed encoder's last layer computes the <cls> / <eos> rows too (AttnParams::q_trim off)
     int misc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // scratch knobs for experiments
 };
 extern Knobs g_knobs;
