@@ -140,6 +140,32 @@ def test_gemm_kernels(micro, dev, M, N, K, epi, f32out, resid):
     assert err <= 2e-3 * acc.abs().max().item() + 1e-5, err
 
 
+def test_gemm_operand_of_4_gib_takes_64_bit_addressing(micro, dev):
+    """gemm_pp_kernel addresses its operands with 32-bit byte offsets; an A operand of exactly 4 GiB (65 536 x 32 768 fp16) must not
+    reach it (round-4 advisor finding: the guard the kernel's comment promised did not exist): the launcher routes it to the ring
+    kernel.  Checked on 48 sampled rows - among them the last ones, whose byte offsets are the ones that would wrap - against fp64."""
+    from opus_pllm_amd import _cabi
+    from opus_pllm_amd.weights import tile_weight
+    cfg, model, _ = micro
+    M, N, K = 65536, 512, 32768
+    assert M * K * 2 == 1 << 32
+    g = torch.Generator(device=dev).manual_seed(3)
+    A = torch.empty(M, K, dtype=torch.float16, device=dev)
+    for r0 in range(0, M, 8192):                                   # (generated in slabs: no 8-GB fp32 temporary)
+        A[r0:r0 + 8192] = (torch.randn(8192, K, generator=g, device=dev) * 0.5).half()
+    W = (torch.randn(N, K, generator=g, device=dev) / K ** 0.5).half()
+    dW = tile_weight(W)
+    out = torch.zeros(M, N, dtype=torch.float16, device=dev)
+    _cabi.check(_cabi.lib().opus_debug_gemm(model._ctx, A.data_ptr(), dW.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 0, None))
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 16), torch.arange(32760, 32776), torch.arange(M - 16, M)]).to(dev)
+    ref = A[rows].double() @ W.double().T
+    err = (out[rows].double() - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item() + 1e-5, err
+    del A, out
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("M,N,K,epi", [
     (1, 256, 4096, 0), (5, 512, 1024, 2), (16, 96, 320, 0), (17, 6144, 4096, 0), (40, 640, 1280, 2), (64, 4096, 4096, 0),
     (64, 28672, 4096, 2), (50, 208, 192, 0), (33, 2048, 512, 2), (60, 4096, 14336, 0),
