@@ -29,6 +29,8 @@ pmc_pair b64 && pmc_pair b1 --batch 1 &&
 python3 bench.py --mixed-lengths --steps 5 --warmup 2 --no-cpu-baseline --no-c2 --no-var-t > $OUT/bench_c3.json 2> $OUT/bench_c3.log &&
 python3 bench.py --new-tokens 128 --steps 5 --warmup 2 --no-cpu-baseline --no-inflight --no-e2e --no-var-t > $OUT/bench_new128.json 2> $OUT/bench_new128.log &&
 python3 bench.py --new-tokens 256 --steps 3 --warmup 1 --no-cpu-baseline --no-inflight --no-e2e --no-var-t > $OUT/bench_new256.json 2> $OUT/bench_new256.log &&
+rocprofv3 --kernel-trace -d $OUT/shapes256 -o p --output-format csv -- python3 bench.py --new-tokens 256 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-c2 --no-inflight --no-e2e --no-var-t > $OUT/shapes256.log 2>&1 &&
+python3 tools/prof_shapes.py $OUT/shapes256 0.5 > $OUT/kernel_shapes_new256.txt && rm -rf $OUT/shapes256 &&
 python3 bench.py --model vicuna_13b --batch 32 --residues 1024 --steps 5 --warmup 2 --no-cpu-baseline --no-c2 --no-var-t > $OUT/bench_c5.json 2> $OUT/bench_c5.log &&
 rocprofv3 --kernel-trace --stats -d $OUT/stats_two_stage -o ts --output-format csv -- python3 tools/two_stage_demo.py --n 4096 > $OUT/two_stage.log 2>&1 &&
 keep_stats $OUT/stats_two_stage $OUT/kernel_stats_two_stage.csv &&
