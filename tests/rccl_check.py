@@ -21,7 +21,11 @@ from opus_pllm_amd import dist                                 # noqa: E402
 
 def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
+    if "MASTER_PORT" not in os.environ:                        # a free port: the rendezvous of a one-rank group is local
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", 0, 1, device=dev, timeout_s=120)
