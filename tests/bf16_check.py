@@ -162,4 +162,74 @@ a1 = model.generate(ids, seqs, max_new_tokens=12, pad_token_id=0)
 a2 = model.generate(ids, seqs, max_new_tokens=12, pad_token_id=0)
 out["full_generate_deterministic"] = bool(torch.equal(a1, a2)) and tuple(a1.shape) == (2, 12)
 out["full_finite"] = bool(torch.isfinite(lg0).all() and torch.isfinite(lg1).all())
+del model
+
+# ---- F: the decode path past 128 cache positions on this build (tests/test_gpu_longctx.py holds the fp16 row): the decode attention
+# alone at 352 cache slots vs an fp64 softmax, and a mid-size model's decode steps at ~350 positions vs prefill of the longer prompt
+import ctypes as C
+nh, nkv, hd, Bq, L = 32, 8, 128, 8, 352
+cfg = opa.OpusConfig(enc_layers=1, enc_dim=64, enc_heads=4, enc_ffn=64, proj_dim=64, dec_layers=1, dec_dim=64, dec_heads=nh, dec_kv_heads=nkv,
+                     dec_head_dim=hd, dec_ffn=64, dec_vocab=64, dec_rope_theta=500000.0, max_batch=Bq, max_enc_tokens=8, max_prompt=400,
+                     max_new_tokens=160).validate()
+ctx = C.c_void_p()
+cc = _cabi.CConfig.from_config(cfg)
+_cabi.check(lib.opus_ctx_create(C.byref(cc), 0, C.byref(ctx)))
+g = torch.Generator().manual_seed(77)
+qkv = torch.randn(Bq, (nh + 2 * nkv) * hd, generator=g).to(BF)
+kh = torch.randn(Bq, nkv, L, hd, generator=g).to(BF)
+vh = torch.randn(Bq, nkv, L, hd, generator=g).to(BF)
+kstart = torch.tensor([0, 7, 33, 130, 0, 64, 200, 1], dtype=torch.int32)
+T0, step = 300, 52
+
+
+def rope64(x, pos):
+    inv = 1.0 / (cfg.dec_rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = (pos[:, None].float() * inv[None, :]).double()
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1)[:, None], torch.cat([ang.sin(), ang.sin()], -1)[:, None]
+    return x * cos + torch.cat([-x[..., hd // 2:], x[..., : hd // 2]], -1) * sin
+
+
+pos = (L - kstart).long()
+q = rope64(qkv[:, : nh * hd].double().view(Bq, nh, hd), pos).to(BF).double()
+kn = rope64(qkv[:, nh * hd: (nh + nkv) * hd].double().view(Bq, nkv, hd), pos).to(BF).double()
+vn = qkv[:, (nh + nkv) * hd:].double().view(Bq, nkv, hd)
+K = torch.cat([kh.double(), kn[:, :, None, :]], 2).repeat_interleave(nh // nkv, 1)
+V = torch.cat([vh.double(), vn[:, :, None, :]], 2).repeat_interleave(nh // nkv, 1)
+sc = torch.einsum("bhd,bhjd->bhj", q, K) * hd ** -0.5
+sc = sc.masked_fill((torch.arange(L + 1)[None, :] < kstart[:, None])[:, None, :], float("-inf"))
+ref = torch.einsum("bhj,bhjd->bhd", torch.softmax(sc, -1), V).reshape(Bq, nh * hd)
+o = torch.zeros(Bq, nh * hd, dtype=BF, device=dev)
+dq, dk, dv, dks = qkv.to(dev), kh.to(dev), vh.to(dev), kstart.to(dev)
+_cabi.check(lib.opus_debug_attn_decode(ctx, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dks.data_ptr(), Bq, T0, step, o.data_ptr(), None, None, None))
+torch.cuda.synchronize()
+out["long_attn_decode_abs"] = float((o.double().cpu() - ref).abs().max())
+lib.opus_ctx_destroy(ctx)
+
+cfg = opa.OpusConfig(enc_layers=2, enc_dim=1280, enc_heads=20, enc_ffn=5120, proj_dim=1024, dec_layers=2, dec_dim=1024, dec_heads=8,
+                     dec_kv_heads=2, dec_head_dim=128, dec_ffn=2816, dec_vocab=4096, max_batch=4, max_enc_tokens=66, max_prompt=360,
+                     max_new_tokens=8).validate()
+model = OpusLlamaForCausalLM(cfg, DeviceWeights.synthetic(cfg, 0, dev), dev)
+seqs = [synth.synth_protein(40 + i, 50 + i) for i in range(4)]
+rows = [synth.synth_prompt_ids(cfg.dec_vocab, i, n_text=n, seq_pos=9) for i, n in enumerate((342, 342 - 150, 342 - 33, 342 - 64))]
+width = max(len(r) for r in rows)
+ids = torch.zeros((4, width), dtype=torch.long)
+mask = torch.zeros((4, width), dtype=torch.bool)
+for i, r in enumerate(rows):
+    ids[i, width - len(r):] = torch.tensor(r)
+    mask[i, width - len(r):] = True
+prot = model.switch_projector_embedding(model.encode_projector_embedding(model.encode_seq2embedding(seqs)))
+emb, mo, _ = model._splice(ids, mask, prot, True)
+assert emb.shape[1] == 349
+lg = model.prefill_logits(emb, mo)
+toks, worst = [], 0.0
+for s in range(4):                                            # slots 349 .. 352: the fourth step opens a new key tile
+    toks.append(lg.argmax(-1))
+    lg = model.decode_logits(toks[-1])
+    ext = torch.cat([emb] + [model.get_model().embed_tokens(t)[:, None, :] for t in toks], dim=1)
+    m2 = torch.cat([mo, torch.ones_like(mo[:, : s + 1])], dim=1)
+    worst = max(worst, rel_l2(lg, model.prefill_logits(ext, m2)))
+    model.prefill_logits(emb, mo)                             # (back to the cache of the original prompt + the steps so far)
+    for t in toks:
+        model.decode_logits(t)
+out["long_decode_vs_prefill"] = worst
 print("BF16_CHECK " + json.dumps(out), flush=True)

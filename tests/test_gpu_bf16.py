@@ -31,3 +31,7 @@ def test_bf16_build_runs_the_path():
     assert o["mid_ids_checked"] >= 16 and o["mid_ids_bad"] == 0, o     # greedy ids equal on every step with oracle margin > 0.4
     # full-size shapes: decode step vs prefill of the longer prompt, observed 4.5e-3 (fp16: 6.6e-4)
     assert o["full_decode_vs_prefill"] < 1.5e-2 and o["full_generate_deterministic"] and o["full_finite"], o
+    # past 128 cache positions (round 5): the decode attention alone at 352 slots (bound = the bf16 attention bound above), and
+    # decode steps at 349 .. 352 positions vs prefill of the longer prompt, rows left-padded by 0 .. 150 (bound as the 96-position form)
+    assert o["long_attn_decode_abs"] <= 2.4e-2, o
+    assert o["long_decode_vs_prefill"] < 1.5e-2, o
