@@ -276,7 +276,9 @@ int opus_last_logits(opus_ctx *ctx, float *d_out, int32_t B, void *stream);
  * instantiated since the context was created - the captured step reads the prompt length from device memory, so a dataset's
  * batches share one graph whatever their T (the reference's loop, eval/run_opus_ddp.py:88-135, brings a new T with every batch);
  * a different number of rows / token budget / sampling setting is another graph (a few are kept).  "graph_replays": decode steps
- * launched from a graph.  "graphs_cached". */
+ * launched from a graph.  "graphs_cached".  "decode_steps": decode steps the generate loops enqueued - with an EOS id or a stop
+ * sequence the loop polls the rows' state with a bounded run-ahead and stops at most 2 steps after the last row finished (HF stops
+ * at once; the extra steps emit pad ids only, the returned ids and n_out are exact). */
 int64_t opus_stat(opus_ctx *ctx, const char *name);
 
 /* Measurement support (bench.py).  With timing enabled (off by default; decode runs eagerly instead of from the

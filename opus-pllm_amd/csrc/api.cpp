@@ -93,6 +93,11 @@ struct opus_ctx {
     float *cs_enc, *cs_dec, *cs_row;
     int32_t *d_kstart, *d_step, *d_next, *d_fin, *d_nunf, *d_eos, *d_plan, *d_pidx, *d_stop, *d_cnt;
     int n_stop = 0;                      // opt-in stop sequence (opus_set_stop_sequence)
+    // "has every row finished?" is polled with a bounded run-ahead (generate_impl): the step's unfinished count lands in pinned host
+    // memory behind an event per step
+    static constexpr int POLL_RING = 4, POLL_LAG = 2;
+    int32_t *h_nunf = nullptr;
+    hipEvent_t poll_ev[POLL_RING] = {nullptr, nullptr, nullptr, nullptr};
     int64_t cache_sl, cache_sb, cache_sh;   // strides (halfs): layer, batch row, kv head
     // decode state
     int cur_B = 0, cur_T = 0;
@@ -114,6 +119,7 @@ struct opus_ctx {
     uint64_t graph_clock = 0;
     int64_t graph_instantiations = 0;    // opus_stat("graph_instantiations")
     int64_t graph_replays = 0;
+    int64_t decode_steps = 0;            // decode steps enqueued by opus_generate_* (eager or from a graph)
     // row-scale fusion (GemmParams::xh_out / row_ssq): one-shot request for the next gemm() and its outcome
     half_t *rq_xh = nullptr;
     int rq_done = 0;
@@ -333,6 +339,8 @@ extern "C" int opus_ctx_create(const opus_config *cfg, int device, opus_ctx **ou
     // the decode attention reads whole 32-slot tiles and masks afterwards: every cache slot must hold finite values
     HIPC(hipMemset(c->kc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
     HIPC(hipMemset(c->vc, 0, (size_t)c->cache_sl * cfg->dec_layers * sizeof(half_t)));
+    HIPC(hipHostMalloc((void **)&c->h_nunf, ((size_t)cfg->max_new_tokens + 4) * sizeof(int32_t), hipHostMallocDefault));
+    for (auto &e : c->poll_ev) HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     *out = c;
     return OPUS_OK;
 }
@@ -359,6 +367,8 @@ extern "C" int opus_ctx_destroy(opus_ctx *c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->proj_big) (void)hipFree(c->proj_big);
     if (c->kv_tmp) (void)hipFree(c->kv_tmp);
+    if (c->h_nunf) (void)hipHostFree(c->h_nunf);
+    for (auto &e : c->poll_ev) if (e) (void)hipEventDestroy(e);
     delete c;
     return OPUS_OK;
 }
@@ -1248,6 +1258,7 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
             produced = i + 1;
             break;
         }
+        ++c->decode_steps;
         if (!use_graph || (i == 0 && !same_graph)) {
             OPC(greedy_body(c, s, max_new, n_eos, pad_id, d_out_ids));   // eager (also warms lazily-set attributes)
         } else {
@@ -1278,14 +1289,18 @@ static int generate_impl(opus_ctx *c, const void *d_embeds, const uint8_t *d_mas
             HIPC(hipGraphLaunch(ge->exec, s));
         }
         produced = i + 1;
-        // HF stops as soon as every row has finished; poll every 8 steps (finished rows emit pad, so
-        // the ids are identical and n_out is computed exactly below).
-        if ((n_eos > 0 || c->n_stop > 0) && (i & 7) == 7) {
-            HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)(i + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            HIPC(hipStreamSynchronize(s));
-            bool done = false;
-            for (int k = 0; k <= i; ++k) if (nunf[k] == 0) { done = true; break; }
-            if (done) break;
+        // HF stops as soon as every row has finished.  The host runs ahead of the GPU, so it polls with a BOUNDED run-ahead instead
+        // of a synchronisation per step: step i's unfinished count is copied to pinned memory behind an event, and before step
+        // i + 1 is enqueued the host waits for step i - 2's event (the GPU still has a step queued: no bubble) and stops when that
+        // count is zero - at most 2 steps are decoded past the last row's EOS (rounds 1-4: a stream synchronisation every 8 steps,
+        // up to 7 wasted steps).  Finished rows emit pad, so the ids are identical and n_out is computed exactly below.
+        if (n_eos > 0 || c->n_stop > 0) {
+            HIPC(hipMemcpyAsync(c->h_nunf + i, c->d_nunf + i, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIPC(hipEventRecord(c->poll_ev[i % opus_ctx::POLL_RING], s));
+            if (i >= opus_ctx::POLL_LAG) {
+                HIPC(hipEventSynchronize(c->poll_ev[(i - opus_ctx::POLL_LAG) % opus_ctx::POLL_RING]));
+                if (c->h_nunf[i - opus_ctx::POLL_LAG] == 0) break;
+            }
         }
     }
     HIPC(hipMemcpyAsync(nunf.data(), c->d_nunf, (size_t)produced * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1612,12 +1627,14 @@ extern "C" int opus_debug_knob(opus_ctx *c, const char *name, int32_t value) {
 
 // Counters of this context (no reference counterpart): "graph_instantiations" = decode-step hipGraphs instantiated since the
 // context was created (one per distinct batch size / token budget / sampling setting, none per prompt length);
-// "graph_replays" = decode steps launched from a graph; "graphs_cached".  Unknown name / null: -1.
+// "graph_replays" = decode steps launched from a graph; "graphs_cached"; "decode_steps" = decode steps opus_generate_* enqueued
+// (with an EOS id or a stop sequence: at most 2 past the step at which the last row finished).  Unknown name / null: -1.
 extern "C" int64_t opus_stat(opus_ctx *c, const char *name) {
     if (!c || !name) return -1;
     if (!strcmp(name, "graph_instantiations")) return c->graph_instantiations;
     if (!strcmp(name, "graph_replays")) return c->graph_replays;
     if (!strcmp(name, "graphs_cached")) return (int64_t)c->graphs.size();
+    if (!strcmp(name, "decode_steps")) return c->decode_steps;
     return -1;
 }
 

@@ -682,6 +682,30 @@ def test_decode_graph_is_shared_across_prompt_lengths(dev, monkeypatch):
         model.stat("no_such_counter")
 
 
+def test_generate_stops_within_two_steps_of_the_last_eos(micro, gold, gold_dir):
+    """HF's loop ends as soon as every row has emitted an EOS id.  Here the host runs ahead of the GPU and polls the rows' state
+    with a bounded run-ahead: the ids and their number are exactly HF's (oracle), and at most 2 decode steps are enqueued past
+    the step at which the last row finished (rounds 1-4 polled every 8 steps: up to 7)."""
+    import oracle
+    cfg, model, W = micro
+    g = gold("generate_micro")
+    seqs = json.load(open(os.path.join(gold_dir, "generate_micro.seqs.json")))
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    free = torch.from_numpy(g["free_ids"])
+    pipe = oracle.OraclePipeline(cfg, W)
+    for k in (1, 4, 6):
+        eos = sorted(set(int(t) for t in free[:, k]))                        # every row emits one of these at step k at the latest
+        ref, _, _ = pipe.generate(ids, seqs, mask, 12, tuple(eos), int(g["pad"]))
+        assert ref.shape[1] <= k + 1
+        for attempt in range(2):                                             # (eager first step + capture, then the cached graph)
+            n0 = model.stat("decode_steps")
+            out = model.generate(ids, seqs, attention_mask=mask, pad_token_id=int(g["pad"]), eos_token_id=eos, do_sample=False,
+                                 max_new_tokens=12).cpu()
+            steps = model.stat("decode_steps") - n0
+            assert torch.equal(out, ref), (k, out, ref)
+            assert steps <= ref.shape[1] + 2, (k, steps, ref.shape)
+
+
 def test_generate_stop_sequence_opt_in(micro, gold, gold_dir):
     """Row N2, "### early-stop as an opt-in": with a stop sequence set, a row is finished once its new ids end with it and
     emits pad afterwards; the ids up to and including the sequence are the free-running ones, rows that never produce it are
