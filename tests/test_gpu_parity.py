@@ -635,12 +635,14 @@ def test_generate_beam_golden(dev, gold, gold_dir):
         model.generate(ids, seqs, attention_mask=mask, num_beams=0, max_new_tokens=4)
 
 
-def test_decode_graph_is_shared_across_prompt_lengths(dev, monkeypatch):
+@pytest.mark.parametrize("preset", ["micro", "micro_opt"])
+def test_decode_graph_is_shared_across_prompt_lengths(dev, monkeypatch, preset):
     """The reference's loop brings a new prompt length with every batch (eval/run_opus_ddp.py:88-135).  The captured decode step
     reads T0 from device memory, so batches of one size share ONE instantiated hipGraph whatever their T: counted here, with
     the ids of every batch equal to eager launches of the same batch.  A different number of rows is another graph (kept beside
     the first: going back to the first size instantiates nothing); more than four sizes evict the least recently used."""
-    cfg = opa.micro(max_prompt=80, max_new_tokens=16)
+    # (micro_opt: the OPT / Galactica decoder, whose learned-position kernel reads the prompt length from the device too)
+    cfg = opa.PRESETS[preset](max_prompt=80, max_new_tokens=16)
     model, _ = make_model(cfg, dev)
     seqs = [synth.synth_protein(20 + 3 * i, i) for i in range(6)]
 
