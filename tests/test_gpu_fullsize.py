@@ -135,6 +135,53 @@ def test_other_decoder_families_at_full_size(preset):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("preset", ["galactica_1_3b", "qwen2_7b"])
+def test_other_decoder_families_past_128_cache_positions(preset):
+    """Row N4 past 128 cache positions, batched (12 rows: the OPT learned-position kernel and Qwen2's q / k / v bias inside the decode
+    attention's slab sum both take the prompt length from the device since round 5): prefill(T = 229) + 4 decode steps (slots
+    229 .. 232: the key tile that opens at slot 224 is the eighth) == prefill of the extended prompt at every step, rows left-padded
+    by 0 .. 130 positions."""
+    from opus_pllm_amd.model import OpusLlamaForCausalLM
+    from opus_pllm_amd.weights import DeviceWeights
+    dev = torch.device("cuda:0")
+    B, T = 12, 229
+    cfg = opa.PRESETS[preset](max_batch=B, max_enc_tokens=66, max_prompt=240, max_new_tokens=8)
+    model = OpusLlamaForCausalLM(cfg, DeviceWeights.synthetic(cfg, 0, dev), dev)
+    try:
+        seqs = [synth.synth_protein(30 + i, 70 + i) for i in range(B)]
+        rows = [synth.synth_prompt_ids(cfg.dec_vocab, i, n_text=T - 7 - (13 * i) % 131, seq_pos=11) for i in range(B)]
+        width = max(len(r) for r in rows)
+        ids = torch.zeros((B, width), dtype=torch.long)
+        mask = torch.zeros((B, width), dtype=torch.bool)
+        for i, r in enumerate(rows):
+            ids[i, width - len(r):] = torch.tensor(r)
+            mask[i, width - len(r):] = True
+        prot = model.switch_projector_embedding(model.encode_projector_embedding(model.encode_seq2embedding(seqs)))
+        emb, mo, _ = model._splice(ids, mask, prot, True)
+        assert emb.shape[1] == T
+        lg = model.prefill_logits(emb, mo)
+        toks, got = [], []
+        for s_ in range(4):
+            toks.append(lg.argmax(-1))
+            lg = model.decode_logits(toks[-1])
+            got.append(lg)
+        for s_ in range(4):
+            ext = torch.cat([emb] + [model.get_model().embed_tokens(t)[:, None, :] for t in toks[: s_ + 1]], dim=1)
+            m2 = torch.cat([mo, torch.ones_like(mo[:, : s_ + 1])], dim=1)
+            ref = model.prefill_logits(ext, m2)
+            rel = float((got[s_] - ref).norm() / ref.norm())
+            assert rel < 5e-3, (preset, s_, rel)                   # (the bound of the short-context form above)
+            t2 = ref.float().topk(2, dim=-1).values
+            decisive = (t2[:, 0] - t2[:, 1]) > 0.05
+            assert torch.equal(got[s_].argmax(-1)[decisive], ref.argmax(-1)[decisive]), (preset, s_)
+        a = model._greedy(emb, mo, 8, [], 0)
+        b = model._greedy(emb, mo, 8, [], 0)                       # graph replay
+        assert torch.equal(a, b)
+    finally:
+        del model
+        torch.cuda.empty_cache()
+
+
 def test_two_contexts_in_flight_share_weights_and_agree(big):
     """`model.new_context()`: a second context on the same weights; two host threads drive one batch each at the same time
     (eval_ddp.py --inflight 2, bench.py `two_in_flight`) and both return the ids a single context returns."""
