@@ -618,10 +618,30 @@ __global__ __launch_bounds__(256) void sample_stage1_kernel(const float *__restr
     const float thr = (1.0f - top_p) / (float)V;
     float z = 0.f, small = 0.f;
     int cnt = 0;
-    for (int i = i0; i < i1; ++i) {
-        const float p = __expf(row[i] * inv_temp - gmax);
-        z += p;
-        if (p > thr) ++cnt; else small += p;
+    // a thread's share (8 values at V = 128 256, 10 at Qwen2's 152 064) stays in registers: ONE pass over the logits and one
+    // exponential per value (round 5; rounds 1-4 read and exponentiated every value twice, once to count and once to compact)
+    constexpr int TR = 16;
+    const bool in_regs = tper <= TR;
+    float pr[TR];
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < TR; ++u) {
+            const int i = i0 + u;
+            pr[u] = (u < tper && i < i1) ? __expf(row[i] * inv_temp - gmax) : 0.f;     // (same expression as the two-pass form)
+        }
+#pragma unroll
+        for (int u = 0; u < TR; ++u) {              // (index order, as the loop below: the same sums)
+            if (u < tper && i0 + u < i1) {
+                z += pr[u];
+                if (pr[u] > thr) ++cnt; else small += pr[u];
+            }
+        }
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const float p = __expf(row[i] * inv_temp - gmax);
+            z += p;
+            if (p > thr) ++cnt; else small += p;
+        }
     }
     s_cnt[tid + 1] = cnt;
     if (tid == 0) s_cnt[0] = 0;
@@ -632,9 +652,15 @@ __global__ __launch_bounds__(256) void sample_stage1_kernel(const float *__restr
     int w = s_cnt[tid];
     float *cp = cand_p + ((int64_t)b * APART + part) * per;
     int32_t *ci = cand_i + ((int64_t)b * APART + part) * per;
-    for (int i = i0; i < i1; ++i) {
-        const float p = __expf(row[i] * inv_temp - gmax);
-        if (p > thr) { cp[w] = p; ci[w] = i; ++w; }
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < TR; ++u)
+            if (u < tper && i0 + u < i1 && pr[u] > thr) { cp[w] = pr[u]; ci[w] = i0 + u; ++w; }
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const float p = __expf(row[i] * inv_temp - gmax);
+            if (p > thr) { cp[w] = p; ci[w] = i; ++w; }
+        }
     }
     z = block_sum256(z, scratch);
     small = block_sum256(small, scratch);
@@ -677,6 +703,40 @@ __global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, 
         return cand_p[o];
     };
     const bool in_lds = nc <= SAMPLE_LDS_CAP;
+    int dummy_id;
+    // kept = candidates with p > lo; CDF inversion in index order over contiguous chunks of the candidate list
+    auto draw = [&](float lo) {
+        const int cper = (nc + 255) / 256;
+        const int c0 = tid * cper, c1 = (c0 + cper < nc ? c0 + cper : nc);
+        float mine = 0.f;
+        for (int c = c0; c < c1; ++c) {
+            const float p = in_lds ? s_p[c] : cand(c, dummy_id);
+            mine += p > lo ? p : 0.f;
+        }
+        s_pref[tid + 1] = mine;
+        if (tid == 0) s_pref[0] = 0.f;
+        __syncthreads();
+        if (tid == 0)
+            for (int t = 1; t <= 256; ++t) s_pref[t] += s_pref[t - 1];
+        __syncthreads();
+        const float total = s_pref[256];
+        const uint64_t h = splitmix64(*seed_p ^ (0x9E3779B97F4A7C15ull * (uint64_t)(b + 1)) ^ ((uint64_t)(*step + 1) << 32));
+        const float target = (float)(h >> 40) * (1.0f / 16777216.0f) * total;          // u in [0,1)
+        if (s_pref[tid] <= target && target < s_pref[tid + 1]) {
+            float run = s_pref[tid];
+            int pick = -1, last_kept = -1;
+            for (int c = c0; c < c1; ++c) {
+                int id;
+                const float p = cand(c, id);
+                if (p > lo) {
+                    last_kept = id;
+                    run += p;
+                    if (target < run) { pick = id; break; }
+                }
+            }
+            chosen[b] = pick >= 0 ? pick : last_kept;
+        }
+    };
     if (in_lds)
         for (int c = tid; c < nc; c += 256) { int id; s_p[c] = cand(c, id); }
     __syncthreads();
@@ -684,6 +744,54 @@ __global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, 
     // top-k: lo_k < (k-th largest p) <= hi_k, i.e. count(p > lo_k) >= k > count(p > hi_k); the tokens that stay are p > lo_k.
     // Every token that can survive the nucleus is a stage-1 candidate (see there), so with fewer than k candidates all of them
     // stay; the other members of the top-k set then carry < k (1 - top_p) / V of the mass and are left out of Z.
+    // Short candidate lists (a handful of tokens at the reference's temperature 0.1; up to EXACT_CAP): both thresholds EXACTLY, by
+    // rank - one O(nc^2 / 256) pass instead of two bisections of 40 block reductions each (round 5: 31.6 -> ~8 us per step at
+    // batch 64).  The same kept sets: a token survives top-k iff fewer than k tokens are more probable (ties with the k-th stay),
+    // and the nucleus iff the ascending cumulative mass up to and including its ties exceeds (1 - top_p) Z.
+    constexpr int EXACT_CAP = 1024;
+    if (in_lds && nc <= EXACT_CAP) {
+        float lok = 0.f;
+        const bool use_k = top_k > 0 && top_k < V && nc > top_k;
+        float mine[EXACT_CAP / 256];
+#pragma unroll
+        for (int q = 0; q < EXACT_CAP / 256; ++q) mine[q] = tid + 256 * q < nc ? s_p[tid + 256 * q] : -1.f;
+        if (use_k) {
+            float dropped = 0.f;                        // largest probability that top-k drops
+#pragma unroll
+            for (int q = 0; q < EXACT_CAP / 256; ++q) {
+                if (mine[q] < 0.f) continue;
+                int above = 0;
+                for (int j = 0; j < nc; ++j) above += s_p[j] > mine[q] ? 1 : 0;
+                if (above >= top_k) dropped = fmaxf(dropped, mine[q]);
+            }
+            lok = block_max256(dropped, scratch);
+        }
+        if (top_k > 0 && top_k < V) {                   // (as below: with top-k the nucleus mass is the survivors' alone)
+            float zz = 0.f;
+            for (int c = tid; c < nc; c += 256) zz += s_p[c] > lok ? s_p[c] : 0.f;
+            Z = block_sum256(zz, scratch);
+            S0 = 0.f;
+        }
+        const float cut_e = (1.0f - top_p) * Z;
+        float dropped = 0.f;                            // largest surviving-top-k probability that the nucleus drops
+#pragma unroll
+        for (int q = 0; q < EXACT_CAP / 256; ++q) {
+            if (mine[q] < 0.f || !(mine[q] > lok)) continue;
+            float sle = S0;
+            for (int j = 0; j < nc; ++j) sle += (s_p[j] <= mine[q] && s_p[j] > lok) ? s_p[j] : 0.f;      // (fixed order)
+            if (!(sle > cut_e)) dropped = fmaxf(dropped, mine[q]);
+        }
+        float lo_e = fmaxf(block_max256(dropped, scratch), lok);
+        // every token that is NOT a stage-1 candidate (p <= (1 - top_p) / V) is dropped too: a consumer that tests all tokens
+        // against this threshold (beam-sample) must not take them for kept when no candidate was dropped
+        lo_e = fmaxf(lo_e, (1.0f - top_p) / (float)V);
+        if (thr_out) {
+            if (tid == 0) thr_out[b] = lo_e;
+            return;
+        }
+        draw(lo_e);
+        return;
+    }
     float lo_k = 0.f;
     if (top_k > 0 && top_k < V) {
         if (nc > top_k) {
@@ -722,37 +830,7 @@ __global__ __launch_bounds__(256) void sample_stage2_kernel(int V, float top_p, 
         if (tid == 0) thr_out[b] = lo;
         return;
     }
-    // kept = candidates with p > lo; CDF inversion in index order over contiguous chunks of the candidate list
-    const int cper = (nc + 255) / 256;
-    const int c0 = tid * cper, c1 = (c0 + cper < nc ? c0 + cper : nc);
-    float mine = 0.f;
-    for (int c = c0; c < c1; ++c) {
-        const float p = pval(c);
-        mine += p > lo ? p : 0.f;
-    }
-    s_pref[tid + 1] = mine;
-    if (tid == 0) s_pref[0] = 0.f;
-    __syncthreads();
-    if (tid == 0)
-        for (int t = 1; t <= 256; ++t) s_pref[t] += s_pref[t - 1];
-    __syncthreads();
-    const float total = s_pref[256];
-    const uint64_t h = splitmix64(*seed_p ^ (0x9E3779B97F4A7C15ull * (uint64_t)(b + 1)) ^ ((uint64_t)(*step + 1) << 32));
-    const float target = (float)(h >> 40) * (1.0f / 16777216.0f) * total;          // u in [0,1)
-    if (s_pref[tid] <= target && target < s_pref[tid + 1]) {
-        float run = s_pref[tid];
-        int pick = -1, last_kept = -1;
-        for (int c = c0; c < c1; ++c) {
-            int id;
-            const float p = cand(c, id);
-            if (p > lo) {
-                last_kept = id;
-                run += p;
-                if (target < run) { pick = id; break; }
-            }
-        }
-        chosen[b] = pick >= 0 ? pick : last_kept;
-    }
+    draw(lo);
 }
 
 hipError_t launch_sample_select(const float *logits, int B, int V, float temperature, float top_p, int top_k, const uint64_t *seed,

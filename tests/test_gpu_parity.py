@@ -838,6 +838,21 @@ def test_beam_sample_draws_match_hf_distribution(micro, dev):
         for freq, want in ((first / first.sum(), ref), (second / second.sum(), want2)):
             noise = 0.5 * float(torch.sqrt(2 * want * (1 - want) / (np.pi * float(first.sum()))).sum())
             assert float((freq - want).abs().sum()) / 2 < 1.5 * noise + 0.01, (t, p, k, noise)
+    # a PEAKED row (one logit far above the rest, as a trained model's): the nucleus search sees a single candidate and drops none -
+    # the tokens below the candidate threshold must still be excluded (a round-5 regression the beam golden caught: with the exact
+    # threshold search every token of non-zero probability counted as kept); min_tokens_to_keep adds each beam's runner-up
+    peaked = base.clone()
+    peaked[0, 7] += 20.0
+    peaked[1, 50] += 20.0
+    logits.copy_(peaked.repeat(B, 1))
+    model._set_top_k(50)
+    ref = oracle.beam_sample_distribution(peaked, torch.tensor([0.0, -0.7]), 0.1, 0.7, 50, M // K)
+    assert int((ref > 0).sum()) == M
+    for step in range(20):
+        s, i = draw([0.0, -0.7], 0.1, 0.7, 3, step)
+        assert bool((ref[i] > 0).all()), (step, i)
+        assert all(sorted(r.tolist()) == sorted((ref > 0).nonzero().flatten().tolist()) for r in i)
+    logits.copy_(base.repeat(B, 1))
     a = draw([0.0, -0.7], 1.0, 0.9, 5, 3)
     b = draw([0.0, -0.7], 1.0, 0.9, 5, 3)
     c = draw([0.0, -0.7], 1.0, 0.9, 6, 3)
