@@ -842,8 +842,8 @@ def test_beam_sample_draws_match_hf_distribution(micro, dev):
     # the tokens below the candidate threshold must still be excluded (a round-5 regression the beam golden caught: with the exact
     # threshold search every token of non-zero probability counted as kept); min_tokens_to_keep adds each beam's runner-up
     peaked = base.clone()
-    peaked[0, 7] += 20.0
-    peaked[1, 50] += 20.0
+    peaked[0, 7] = base[0].max() + 7.0                        # (runner-up 70 nats behind at temperature 0.1: still > 0 in fp32)
+    peaked[1, 50] = base[1].max() + 7.0
     logits.copy_(peaked.repeat(B, 1))
     model._set_top_k(50)
     ref = oracle.beam_sample_distribution(peaked, torch.tensor([0.0, -0.7]), 0.1, 0.7, 50, M // K)
