@@ -2305,7 +2305,14 @@ static hipError_t launch_ring(const GemmParams &p, hipStream_t s, bool allow_spl
     const int bm = cdiv(p.M, BM), bn = cdiv(p.N, BN), KS = p.K / GBK;
     int ks = 1;
     if (allow_split && p.ws && bm * bn < 200) {
-        ks = cdiv(256, bm * bn);
+        // k-parts that fit ONE round of 256 workgroups (floor) rather than spill into a second one (ceil: 150 tiles x 2 = 300),
+        // except where that would leave a long-K GEMM unsplit: measured (profiles/r05_ring_ks.txt, ceil -> floor) ESM QKV at 514 rows
+        // 31.0 -> 24.7 us, fc2 32.9 -> 26.7, wo at 1 028 rows 26.0 -> 21.6 - no slabs / reduce launch, or one round instead of
+        // 1.2 - but fc2 at 2 056 rows (170 tiles, K = 5120) 63.9 -> 73.1 and the batch-8 prefill (192 tiles, K >= 4096) +6 us per
+        // GEMM: there the second half-round of k-parts is worth more than the reduce costs.
+        const int ks_floor = 256 / (bm * bn);
+        ks = (ks_floor >= 2 || p.K <= 2048) ? ks_floor : cdiv(256, bm * bn);
+        if (ks < 1) ks = 1;
         ks = ks > 16 ? 16 : ks;
         if (ks > KS / 8) ks = KS / 8;
         while (ks > 1 && (int64_t)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
